@@ -1,0 +1,426 @@
+/*
+ * mdc_oracle.c -- plain-C CPU restatement of the reference's bulk record-parsing path.
+ *
+ * TEST INFRASTRUCTURE ONLY: this file is the parity checker and the timed CPU "port"
+ * baseline.  The product library never includes, links or calls it.
+ *
+ * Pinning: the reference ships no tests or golden vectors for this path.  This
+ * restatement is pinned (a) against the reference's own public/_public.cpp compiled in
+ * place by oracle/Makefile (oracle/_ref/libmdc_ref.so, same C interface) on randomized and
+ * adversarial inputs, and (b) against the fixtures under tests/golden/ that were generated
+ * from that reference build by tests/golden/make_golden.py.
+ *
+ * Every function cites the reference lines it follows (paths relative to the reference
+ * root).  Number conversion is the C library's strtol/strtoul/strtod/strtof, which is what
+ * the reference's std::sto* calls reduce to (libstdc++ __stoa).
+ */
+#define _GNU_SOURCE
+#include "mdc_oracle.h"
+#include "orc_builder.h"
+
+#include <errno.h>
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ small helpers */
+
+typedef struct {
+    uint8_t *p;
+    size_t n, cap;
+} bytebuf;
+
+static void bb_reserve(bytebuf *b, size_t extra) {
+    if (b->n + extra <= b->cap) return;
+    size_t nc = b->cap ? b->cap * 2 : 256;
+    while (nc < b->n + extra) nc *= 2;
+    b->p = (uint8_t *)realloc(b->p, nc);
+    b->cap = nc;
+}
+static void bb_assign(bytebuf *b, const uint8_t *s, size_t n) {
+    b->n = 0;
+    bb_reserve(b, n + 1);
+    if (n) memmove(b->p, s, n);
+    b->n = n;
+}
+
+/* std::string::find(needle, from) on raw bytes; returns (size_t)-1 when absent */
+static size_t bytes_find(const uint8_t *h, size_t hn, const uint8_t *nd, size_t nn, size_t from) {
+    if (from > hn) return (size_t)-1;
+    if (nn == 0) return from;
+    if (hn - from < nn) return (size_t)-1;
+    const uint8_t *r = (const uint8_t *)memmem(h + from, hn - from, nd, nn);
+    return r ? (size_t)(r - h) : (size_t)-1;
+}
+
+/* ------------------------------------------------------------------ A1 readline */
+
+/* cifile::readline, public/_public.cpp:866-892, applied repeatedly until it returns false.
+ * getline() strips the '\n'; a line that hits EOF before a '\n' sets eofbit and is dropped
+ * (:876); lines are re-joined with '\n' (:888); the record is complete when the
+ * accumulated buffer ends with endbz (:885), or after the first line when endbz is empty
+ * (:880-881).  buf.find(endbz, buf.length()-endbz.length()) wraps to npos when the buffer
+ * is shorter than endbz. */
+int64_t ORC_FN(split_records)(const uint8_t *data, size_t n, const char *endbz, uint64_t *start,
+                              uint64_t *len, int64_t cap) {
+    size_t el = endbz ? strlen(endbz) : 0;
+    size_t pos = 0;      /* stream position */
+    size_t recstart = 0; /* where the accumulated buffer begins */
+    int64_t count = 0;
+    for (;;) {
+        const uint8_t *nl = pos < n ? (const uint8_t *)memchr(data + pos, '\n', n - pos) : NULL;
+        if (!nl) break; /* eof while reading this line */
+        size_t lineend = (size_t)(nl - data);
+        size_t buflen = lineend - recstart;
+        int complete;
+        if (el == 0)
+            complete = 1;
+        else
+            complete = buflen >= el && memcmp(data + lineend - el, endbz, el) == 0;
+        pos = lineend + 1;
+        if (complete) {
+            if (count < cap) {
+                if (start) start[count] = recstart;
+                if (len) len[count] = buflen;
+            }
+            ++count;
+            recstart = pos;
+        }
+    }
+    return count;
+}
+
+/* ------------------------------------------------------------------ A2 getxmlbuffer */
+
+/* getxmlbuffer(const string&,const string&,string&,int), public/_public.cpp:461-481.
+ * Both tags are searched from offset 0 independently (:466, :469).  itmplen is computed
+ * in size_t and narrowed to int (:476): a close tag in front of the open tag gives a
+ * negative int, which skips the clip (:477) and becomes npos in substr (:478), i.e. the
+ * rest of the record. */
+static int getxml_span(const uint8_t *rec, size_t reclen, const char *name, int ilen, size_t *pos,
+                       size_t *len) {
+    size_t nl = strlen(name);
+    uint8_t st[40 + 256], en[40 + 256];
+    if (nl > 256) return 0;
+    st[0] = '<';
+    memcpy(st + 1, name, nl);
+    st[1 + nl] = '>';
+    en[0] = '<';
+    en[1] = '/';
+    memcpy(en + 2, name, nl);
+    en[2 + nl] = '>';
+    size_t sl = nl + 2, enl = nl + 3;
+
+    size_t startp = bytes_find(rec, reclen, st, sl, 0);
+    if (startp == (size_t)-1) return 0;
+    size_t endp = bytes_find(rec, reclen, en, enl, 0);
+    if (endp == (size_t)-1) return 0;
+
+    int itmplen = (int)(endp - startp - sl);
+    if (ilen > 0 && ilen < itmplen) itmplen = ilen;
+    size_t from = startp + sl;
+    size_t cnt = (size_t)itmplen; /* negative -> huge */
+    size_t avail = reclen - from;
+    if (cnt > avail) cnt = avail;
+    *pos = from;
+    *len = cnt;
+    return 1;
+}
+
+int ORC_FN(getxmlbuffer)(const uint8_t *rec, size_t reclen, const char *name, int ilen,
+                         uint8_t *out, size_t outcap, size_t *outlen) {
+    size_t p = 0, l = 0;
+    if (!getxml_span(rec, reclen, name, ilen, &p, &l)) return 0;
+    if (out && outcap) memcpy(out, rec + p, l < outcap ? l : outcap);
+    if (outlen) *outlen = l;
+    return 1;
+}
+
+/* ------------------------------------------------------------------ A3 picknumber */
+
+/* picknumber(const string&,string&,bool,bool), public/_public.cpp:178-204.
+ * isdigit() in the C locale (the reference never calls setlocale) is '0'..'9' only. */
+size_t ORC_FN(picknumber)(const uint8_t *src, size_t n, uint8_t *dst, int bsigned, int bdot) {
+    size_t o = 0;
+    for (size_t i = 0; i < n; ++i) {
+        uint8_t cc = src[i];
+        if (bsigned && (cc == '+' || cc == '-')) {
+            dst[o++] = cc;
+            continue;
+        }
+        if (bdot && cc == '.') {
+            dst[o++] = cc;
+            continue;
+        }
+        if (cc >= '0' && cc <= '9') dst[o++] = cc;
+    }
+    return o;
+}
+
+/* ------------------------------------------------------------------ A9/A10 trims, case */
+
+/* string overloads, public/_public.cpp:24-31 (deletelchr), :52-59 (deleterchr),
+ * :69-75 (deletelrchr).  deleterchr's "if (pos!=0)" test keeps trailing cc characters
+ * when the last other character sits at index 0; npos+1 wraps to 0 for an all-cc string. */
+size_t ORC_FN(trim)(uint8_t *s, size_t n, int cc, int which) {
+    uint8_t c = (uint8_t)cc;
+    if (which == 0 || which == 2) {
+        size_t pos = 0;
+        while (pos < n && s[pos] == c) ++pos;
+        if (pos == n) pos = (size_t)-1; /* find_first_not_of -> npos */
+        if (pos != 0) {
+            size_t cut = pos == (size_t)-1 ? n : pos; /* replace(0,npos,"") erases all */
+            memmove(s, s + cut, n - cut);
+            n -= cut;
+        }
+    }
+    if (which == 1 || which == 2) {
+        size_t pos = (size_t)-1; /* find_last_not_of */
+        for (size_t i = n; i-- > 0;)
+            if (s[i] != c) {
+                pos = i;
+                break;
+            }
+        if (pos != 0) {
+            size_t keep = pos + 1; /* npos+1 == 0 */
+            if (keep < n) n = keep;
+        }
+    }
+    return n;
+}
+
+/* toupper(string&), public/_public.cpp:91-99: ASCII a-z only */
+static void ascii_upper(uint8_t *s, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+        if (s[i] >= 'a' && s[i] <= 'z') s[i] = (uint8_t)(s[i] - 32);
+}
+
+/* ------------------------------------------------------------------ A7 typed conversion */
+
+/* The typed getxmlbuffer / ccmdstr::getvalue overloads, public/_public.cpp:506-625 and
+ * :339-446: filter with picknumber, convert with std::sto*, map any exception to false.
+ * libstdc++'s __stoa: no conversion -> invalid_argument; errno==ERANGE (or an int range
+ * check for stoi) -> out_of_range. */
+int ORC_FN(convert)(const uint8_t *s, size_t n, int type, uint64_t *out8) {
+    if (type == ORC_T_NONE) return 0;
+    if (type == ORC_T_BOOL) {
+        /* :506-517 / :435-446 */
+        int istrue = 0;
+        if (n == 4) {
+            uint8_t t[4];
+            memcpy(t, s, 4);
+            ascii_upper(t, 4);
+            istrue = memcmp(t, "TRUE", 4) == 0;
+        }
+        *out8 = (uint64_t)istrue;
+        return 1;
+    }
+    int bsigned = (type == ORC_T_I32 || type == ORC_T_I64 || type == ORC_T_F64 || type == ORC_T_F32);
+    int bdot = (type == ORC_T_F64 || type == ORC_T_F32);
+    char *f = (char *)malloc(n + 1);
+    size_t fl = ORC_FN(picknumber)(s, n, (uint8_t *)f, bsigned, bdot);
+    f[fl] = 0;
+    char *end = NULL;
+    int ok = 0;
+    errno = 0;
+    switch (type) {
+    case ORC_T_I32:
+    case ORC_T_U32: { /* both go through stoi (:527, :545) */
+        long v = strtol(f, &end, 10);
+        if (end != f && errno != ERANGE && v >= INT_MIN && v <= INT_MAX) {
+            if (type == ORC_T_I32)
+                *out8 = (uint64_t)(int64_t)(int)v;
+            else
+                *out8 = (uint64_t)(unsigned int)(int)v;
+            ok = 1;
+        }
+        break;
+    }
+    case ORC_T_I64: { /* stol :563 */
+        long v = strtol(f, &end, 10);
+        if (end != f && errno != ERANGE) {
+            *out8 = (uint64_t)v;
+            ok = 1;
+        }
+        break;
+    }
+    case ORC_T_U64: { /* stoul :581 */
+        unsigned long v = strtoul(f, &end, 10);
+        if (end != f && errno != ERANGE) {
+            *out8 = (uint64_t)v;
+            ok = 1;
+        }
+        break;
+    }
+    case ORC_T_F64: { /* stod :599 */
+        double v = strtod(f, &end);
+        if (end != f && errno != ERANGE) {
+            memcpy(out8, &v, 8);
+            ok = 1;
+        }
+        break;
+    }
+    case ORC_T_F32: { /* stof :617 */
+        float v = strtof(f, &end);
+        if (end != f && errno != ERANGE) {
+            uint32_t b;
+            memcpy(&b, &v, 4);
+            *out8 = b;
+            ok = 1;
+        }
+        break;
+    }
+    default:
+        break;
+    }
+    free(f);
+    return ok;
+}
+
+/* ------------------------------------------------------------------ A4 xmltodb path */
+
+/* _xmltodb record loop (tools/xmltodb.cpp:263-268) + splitbuffer (:492-522).
+ * temp lives for one record (:494); getxmlbuffer's return value is ignored so temp keeps
+ * the previous column's filtered value when a tag is missing (:498-499); date columns are
+ * filtered with picknumber(false,false) (:503-506), number columns with (true,true)
+ * (:507-511); the bound value is temp.c_str(), i.e. cut at the first NUL (:518). */
+orc_batch *ORC_FN(parse_xml)(const uint8_t *data, size_t n, const char *endbz, const orc_col *cols,
+                             int ncols, const int *typed, int carry) {
+    int *ty = (int *)calloc((size_t)ncols + 1, sizeof(int));
+    default_typed(cols, ncols, typed, ty);
+    builder *B = builder_new(ncols, ty);
+    orc_batch *b = &B->b;
+
+    int64_t nrec = ORC_FN(split_records)(data, n, endbz, NULL, NULL, 0);
+    uint64_t *rs = (uint64_t *)malloc(((size_t)nrec + 1) * 8);
+    uint64_t *rl = (uint64_t *)malloc(((size_t)nrec + 1) * 8);
+    ORC_FN(split_records)(data, n, endbz, rs, rl, nrec);
+
+    bytebuf temp = {0, 0, 0};
+    for (int64_t r = 0; r < nrec; ++r) {
+        while (r >= B->cap_rows) builder_grow_rows(B);
+        const uint8_t *rec = data + rs[r];
+        size_t reclen = (size_t)rl[r];
+        b->rec_off[r] = rs[r];
+        b->rec_off[r + 1] = rs[r] + rl[r] + 1;
+        temp.n = 0; /* string temp; */
+        for (int c = 0; c < ncols; ++c) {
+            size_t p = 0, l = 0;
+            int found = getxml_span(rec, reclen, cols[c].colname, cols[c].collen, &p, &l);
+            if (found) {
+                bb_assign(&temp, rec + p, l);
+                b->found[r * b->words_per_row + (c >> 5)] |= 1u << (c & 31);
+            } else if (!carry) {
+                temp.n = 0;
+            }
+            if (strcmp(cols[c].datatype, "date") == 0)
+                temp.n = ORC_FN(picknumber)(temp.p, temp.n, temp.p, 0, 0);
+            else if (strcmp(cols[c].datatype, "number") == 0)
+                temp.n = ORC_FN(picknumber)(temp.p, temp.n, temp.p, 1, 1);
+            size_t cl = temp.n;
+            if (carry && cl) { /* vcolvalue[i] = temp.c_str(); */
+                const uint8_t *z = (const uint8_t *)memchr(temp.p, 0, cl);
+                if (z) cl = (size_t)(z - temp.p);
+            }
+            builder_put_cell(B, r, c, temp.p, cl);
+            if (ty[c] != ORC_T_NONE && (carry || found)) {
+                uint64_t v = 0;
+                if (ORC_FN(convert)(temp.p, cl, ty[c], &v)) {
+                    b->val[c][r] = v;
+                    b->valid[r * b->words_per_row + (c >> 5)] |= 1u << (c & 31);
+                }
+            }
+        }
+    }
+    b->rows = nrec;
+    free(temp.p);
+    free(rs);
+    free(rl);
+    free(ty);
+    return b;
+}
+
+orc_batch *ORC_FN(parse_xml_file)(const char *path, const char *endbz, const orc_col *cols,
+                                  int ncols, const int *typed, int carry) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return NULL;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    uint8_t *buf = (uint8_t *)malloc((size_t)sz + 1);
+    size_t got = fread(buf, 1, (size_t)sz, f);
+    fclose(f);
+    orc_batch *b = ORC_FN(parse_xml)(buf, got, endbz, cols, ncols, typed, carry);
+    free(buf);
+    return b;
+}
+
+/* ------------------------------------------------------------------ A8 delimited path */
+
+/* ccmdstr::splittocmd (public/_public.cpp:274-302) on every readline("") line, then
+ * getvalue(ii,string&,ilen) (:304-317) for the cell and the typed getvalue overloads
+ * (:339-446) for the value.  The search restarts after each separator (:291) so separators
+ * never overlap; the text after the last separator is always a field (:295-299). */
+orc_batch *ORC_FN(parse_csv)(const uint8_t *data, size_t n, const char *sep, int bdelspace,
+                             int nfields, const int *ilen, const int *typed) {
+    int *ty = (int *)calloc((size_t)nfields + 1, sizeof(int));
+    for (int c = 0; c < nfields; ++c) ty[c] = typed ? typed[c] : ORC_T_NONE;
+    builder *B = builder_new(nfields, ty);
+    orc_batch *b = &B->b;
+    size_t sl = strlen(sep);
+
+    int64_t nrec = ORC_FN(split_records)(data, n, "", NULL, NULL, 0);
+    uint64_t *rs = (uint64_t *)malloc(((size_t)nrec + 1) * 8);
+    uint64_t *rl = (uint64_t *)malloc(((size_t)nrec + 1) * 8);
+    ORC_FN(split_records)(data, n, "", rs, rl, nrec);
+
+    bytebuf fld = {0, 0, 0};
+    for (int64_t r = 0; r < nrec; ++r) {
+        while (r >= B->cap_rows) builder_grow_rows(B);
+        const uint8_t *rec = data + rs[r];
+        size_t reclen = (size_t)rl[r];
+        b->rec_off[r] = rs[r];
+        b->rec_off[r + 1] = rs[r] + rl[r] + 1;
+        size_t pos = 0;
+        int done = 0; /* set once the trailing field has been consumed */
+        for (int c = 0; c < nfields; ++c) {
+            if (done) { /* ii >= m_cmdstr.size(): getvalue returns false */
+                builder_put_cell(B, r, c, NULL, 0);
+                continue;
+            }
+            size_t pos1 = bytes_find(rec, reclen, (const uint8_t *)sep, sl, pos);
+            size_t flen;
+            if (pos1 == (size_t)-1) {
+                flen = reclen - pos;
+                done = 1;
+            } else {
+                flen = pos1 - pos;
+            }
+            bb_assign(&fld, rec + pos, flen);
+            if (pos1 != (size_t)-1) pos = pos1 + sl;
+            if (bdelspace) fld.n = ORC_FN(trim)(fld.p, fld.n, ' ', 2);
+            b->found[r * b->words_per_row + (c >> 5)] |= 1u << (c & 31);
+            size_t cl = fld.n;
+            if (ilen && ilen[c] > 0 && (size_t)ilen[c] < cl) cl = (size_t)ilen[c];
+            builder_put_cell(B, r, c, fld.p, cl);
+            if (ty[c] != ORC_T_NONE) {
+                uint64_t v = 0;
+                if (ORC_FN(convert)(fld.p, cl, ty[c], &v)) {
+                    b->val[c][r] = v;
+                    b->valid[r * b->words_per_row + (c >> 5)] |= 1u << (c & 31);
+                }
+            }
+        }
+    }
+    b->rows = nrec;
+    free(fld.p);
+    free(rs);
+    free(rl);
+    free(ty);
+    return b;
+}
+
+void ORC_FN(batch_free)(orc_batch *b) { builder_free(b); }
+
+const char *ORC_FN(kind)(void) { return "port"; }

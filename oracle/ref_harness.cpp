@@ -1,0 +1,309 @@
+/*
+ * ref_harness.cpp -- wraps the reference's own public/_public.cpp (compiled from where it
+ * lies under the reference tree, never copied) behind the C interface of mdc_oracle.h with
+ * the prefix ref_.
+ *
+ * TEST INFRASTRUCTURE ONLY: validates oracle/mdc_oracle.c, generates tests/golden/ and is
+ * the "reference" CPU baseline.  Built by oracle/Makefile into oracle/_ref/ (git-ignored).
+ *
+ * Everything that computes a result here is a call into namespace idc of the reference:
+ * cifile::readline, getxmlbuffer (all overloads), picknumber, ccmdstr, deletel/r/lrchr.
+ * The only restated code is the 12-line column loop of splitbuffer
+ * (tools/xmltodb.cpp:492-522), because xmltodb.cpp itself needs Oracle OCI headers and
+ * libclntsh, which this image does not have.
+ */
+#include "_public.h" /* -I<reference>/public */
+
+#define ORC_PREFIX ref_
+#include "mdc_oracle.h"
+#include "orc_builder.h"
+
+#include <unistd.h>
+
+using namespace idc;
+
+namespace {
+
+std::string write_tmp(const uint8_t *data, size_t n) {
+    const char *dir = getenv("TMPDIR");
+    std::string path = std::string(dir && *dir ? dir : "/tmp") + "/mdc_ref_XXXXXX";
+    int fd = mkstemp(&path[0]);
+    if (fd < 0) return "";
+    size_t off = 0;
+    while (off < n) {
+        ssize_t w = write(fd, data + off, n - off);
+        if (w <= 0) break;
+        off += (size_t)w;
+    }
+    close(fd);
+    return path;
+}
+
+/* a tag name that occurs in s neither as <name> nor as </name> */
+std::string free_tag(const std::string &s) {
+    for (int i = 0;; ++i) {
+        std::string nm = "q" + std::to_string(i);
+        if (s.find("<" + nm + ">") == std::string::npos && s.find("</" + nm + ">") == std::string::npos)
+            return nm;
+    }
+}
+
+void default_typed_cols(const orc_col *cols, int ncols, const int *typed, int *out) {
+    for (int c = 0; c < ncols; ++c) {
+        if (typed)
+            out[c] = typed[c];
+        else if (strcmp(cols[c].datatype, "number") == 0)
+            out[c] = ORC_T_F64;
+        else if (strcmp(cols[c].datatype, "date") == 0)
+            out[c] = ORC_T_I64;
+        else
+            out[c] = ORC_T_NONE;
+    }
+}
+
+/* the typed overload of the reference applied to a text: wrap it in a tag the text does not
+ * contain and call getxmlbuffer(xml, tag, T&) (public/_public.cpp:506-625) */
+bool convert_text(const std::string &text, int type, uint64_t *out8) {
+    std::string tag = free_tag(text);
+    std::string xml = "<" + tag + ">" + text + "</" + tag + ">";
+    switch (type) {
+    case ORC_T_I32: {
+        int v = 0;
+        if (!getxmlbuffer(xml, tag, v)) return false;
+        *out8 = (uint64_t)(int64_t)v;
+        return true;
+    }
+    case ORC_T_U32: {
+        unsigned int v = 0;
+        if (!getxmlbuffer(xml, tag, v)) return false;
+        *out8 = (uint64_t)v;
+        return true;
+    }
+    case ORC_T_I64: {
+        long v = 0;
+        if (!getxmlbuffer(xml, tag, v)) return false;
+        *out8 = (uint64_t)v;
+        return true;
+    }
+    case ORC_T_U64: {
+        unsigned long v = 0;
+        if (!getxmlbuffer(xml, tag, v)) return false;
+        *out8 = (uint64_t)v;
+        return true;
+    }
+    case ORC_T_F64: {
+        double v = 0;
+        if (!getxmlbuffer(xml, tag, v)) return false;
+        memcpy(out8, &v, 8);
+        return true;
+    }
+    case ORC_T_F32: {
+        float v = 0;
+        if (!getxmlbuffer(xml, tag, v)) return false;
+        uint32_t b;
+        memcpy(&b, &v, 4);
+        *out8 = b;
+        return true;
+    }
+    case ORC_T_BOOL: {
+        bool v = false;
+        if (!getxmlbuffer(xml, tag, v)) return false;
+        *out8 = v ? 1 : 0;
+        return true;
+    }
+    default:
+        return false;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int64_t ref_split_records(const uint8_t *data, size_t n, const char *endbz, uint64_t *start,
+                          uint64_t *len, int64_t cap) {
+    std::string path = write_tmp(data, n);
+    if (path.empty()) return -1;
+    cifile ifile;
+    int64_t count = 0;
+    if (ifile.open(path)) {
+        std::string buf;
+        uint64_t pos = 0;
+        while (ifile.readline(buf, endbz ? endbz : "")) {
+            if (count < cap) {
+                if (start) start[count] = pos;
+                if (len) len[count] = buf.length();
+            }
+            pos += buf.length() + 1;
+            ++count;
+        }
+        ifile.close();
+    }
+    unlink(path.c_str());
+    return count;
+}
+
+int ref_getxmlbuffer(const uint8_t *rec, size_t reclen, const char *name, int ilen, uint8_t *out,
+                     size_t outcap, size_t *outlen) {
+    std::string xml((const char *)rec, reclen), value;
+    if (!getxmlbuffer(xml, name, value, ilen)) return 0;
+    if (out && outcap) memcpy(out, value.data(), value.length() < outcap ? value.length() : outcap);
+    if (outlen) *outlen = value.length();
+    return 1;
+}
+
+size_t ref_picknumber(const uint8_t *src, size_t n, uint8_t *dst, int bsigned, int bdot) {
+    std::string s((const char *)src, n), d;
+    picknumber(s, d, bsigned != 0, bdot != 0);
+    memcpy(dst, d.data(), d.length());
+    return d.length();
+}
+
+int ref_convert(const uint8_t *s, size_t n, int type, uint64_t *out8) {
+    return convert_text(std::string((const char *)s, n), type, out8) ? 1 : 0;
+}
+
+size_t ref_trim(uint8_t *s, size_t n, int cc, int which) {
+    std::string str((const char *)s, n);
+    if (which == 0)
+        deletelchr(str, cc);
+    else if (which == 1)
+        deleterchr(str, cc);
+    else
+        deletelrchr(str, cc);
+    memcpy(s, str.data(), str.length());
+    return str.length();
+}
+
+orc_batch *ref_parse_xml_file(const char *path, const char *endbz, const orc_col *cols, int ncols,
+                              const int *typed, int carry) {
+    std::vector<int> ty(ncols + 1);
+    default_typed_cols(cols, ncols, typed, ty.data());
+    cifile ifile;
+    if (!ifile.open(path)) return nullptr;
+    builder *B = builder_new(ncols, ty.data());
+    orc_batch *b = &B->b;
+
+    std::vector<std::string> vcolvalue(ncols); /* as preparesql(), tools/xmltodb.cpp:424 */
+    std::string xmlbuffer;
+    uint64_t pos = 0;
+    int64_t r = 0;
+    while (ifile.readline(xmlbuffer, endbz ? endbz : "")) { /* tools/xmltodb.cpp:264 */
+        while (r >= B->cap_rows) builder_grow_rows(B);
+        b->rec_off[r] = pos;
+        pos += xmlbuffer.length() + 1;
+        b->rec_off[r + 1] = pos;
+
+        std::string temp; /* splitbuffer, tools/xmltodb.cpp:494 */
+        for (int i = 0; i < ncols; ++i) {
+            bool found;
+            if (carry) {
+                found = getxmlbuffer(xmlbuffer, cols[i].colname, temp, cols[i].collen);
+            } else {
+                temp.clear();
+                found = getxmlbuffer(xmlbuffer, cols[i].colname, temp, cols[i].collen);
+            }
+            if (strcmp(cols[i].datatype, "date") == 0)
+                picknumber(temp, temp, false, false);
+            else if (strcmp(cols[i].datatype, "number") == 0)
+                picknumber(temp, temp, true, true);
+            if (carry)
+                vcolvalue[i] = temp.c_str();
+            else
+                vcolvalue[i] = temp;
+
+            if (found) b->found[r * b->words_per_row + (i >> 5)] |= 1u << (i & 31);
+            builder_put_cell(B, r, i, (const uint8_t *)vcolvalue[i].data(), vcolvalue[i].length());
+            if (ty[i] != ORC_T_NONE && (carry || found)) {
+                uint64_t v = 0;
+                if (convert_text(vcolvalue[i], ty[i], &v)) {
+                    b->val[i][r] = v;
+                    b->valid[r * b->words_per_row + (i >> 5)] |= 1u << (i & 31);
+                }
+            }
+        }
+        ++r;
+    }
+    b->rows = r;
+    return b;
+}
+
+orc_batch *ref_parse_xml(const uint8_t *data, size_t n, const char *endbz, const orc_col *cols,
+                         int ncols, const int *typed, int carry) {
+    std::string path = write_tmp(data, n);
+    if (path.empty()) return nullptr;
+    orc_batch *b = ref_parse_xml_file(path.c_str(), endbz, cols, ncols, typed, carry);
+    unlink(path.c_str());
+    return b;
+}
+
+orc_batch *ref_parse_csv(const uint8_t *data, size_t n, const char *sep, int bdelspace, int nfields,
+                         const int *ilen, const int *typed) {
+    std::string path = write_tmp(data, n);
+    if (path.empty()) return nullptr;
+    std::vector<int> ty(nfields + 1);
+    for (int c = 0; c < nfields; ++c) ty[c] = typed ? typed[c] : ORC_T_NONE;
+    cifile ifile;
+    if (!ifile.open(path)) {
+        unlink(path.c_str());
+        return nullptr;
+    }
+    builder *B = builder_new(nfields, ty.data());
+    orc_batch *b = &B->b;
+    std::string line, cell;
+    ccmdstr cmd;
+    uint64_t pos = 0;
+    int64_t r = 0;
+    while (ifile.readline(line)) {
+        while (r >= B->cap_rows) builder_grow_rows(B);
+        b->rec_off[r] = pos;
+        pos += line.length() + 1;
+        b->rec_off[r + 1] = pos;
+        cmd.splittocmd(line, sep, bdelspace != 0);
+        for (int c = 0; c < nfields; ++c) {
+            cell.clear();
+            bool found = cmd.getvalue(c, cell, ilen ? ilen[c] : 0);
+            if (!found) cell.clear();
+            if (found) b->found[r * b->words_per_row + (c >> 5)] |= 1u << (c & 31);
+            builder_put_cell(B, r, c, (const uint8_t *)cell.data(), cell.length());
+            if (found && ty[c] != ORC_T_NONE) {
+                uint64_t v = 0;
+                bool ok = convert_text(cell, ty[c], &v);
+                if (!ilen || ilen[c] <= 0) {
+                    /* unclipped: must agree with the ccmdstr::getvalue overload itself */
+                    uint64_t w = 0;
+                    bool ok2 = false;
+                    switch (ty[c]) {
+                    case ORC_T_I32: { int t = 0; ok2 = cmd.getvalue(c, t); w = (uint64_t)(int64_t)t; break; }
+                    case ORC_T_U32: { unsigned int t = 0; ok2 = cmd.getvalue(c, t); w = t; break; }
+                    case ORC_T_I64: { long t = 0; ok2 = cmd.getvalue(c, t); w = (uint64_t)t; break; }
+                    case ORC_T_U64: { unsigned long t = 0; ok2 = cmd.getvalue(c, t); w = t; break; }
+                    case ORC_T_F64: { double t = 0; ok2 = cmd.getvalue(c, t); memcpy(&w, &t, 8); break; }
+                    case ORC_T_F32: { float t = 0; ok2 = cmd.getvalue(c, t); uint32_t u; memcpy(&u, &t, 4); w = u; break; }
+                    case ORC_T_BOOL: { bool t = false; ok2 = cmd.getvalue(c, t); w = t ? 1 : 0; break; }
+                    default: break;
+                    }
+                    if (ok != ok2 || (ok && v != w)) {
+                        fprintf(stderr, "ref_parse_csv: getxmlbuffer/getvalue overloads disagree\n");
+                        abort();
+                    }
+                }
+                if (ok) {
+                    b->val[c][r] = v;
+                    b->valid[r * b->words_per_row + (c >> 5)] |= 1u << (c & 31);
+                }
+            }
+        }
+        ++r;
+    }
+    b->rows = r;
+    ifile.close();
+    unlink(path.c_str());
+    return b;
+}
+
+void ref_batch_free(orc_batch *b) { builder_free(b); }
+
+const char *ref_kind(void) { return "reference"; }
+
+} /* extern "C" */

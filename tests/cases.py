@@ -1,0 +1,268 @@
+"""Seeded input builders shared by the CPU and GPU parity tests.
+
+Three families:
+  * `probe_*`  -- hand-written known-answer inputs for every quirk of the reference path
+                  (independent first-open/first-close search, negative length, clip before
+                  filter, carry-forward, dropped unterminated tail, '\r' kept, trim bug ...).
+  * `mutated_xml` / `soup_xml` -- random records built from a schema with every kind of
+                  damage the format allows, and unstructured token soup.
+  * `fuzz_csv` -- delimited lines with multi-byte separators, blanks and odd numbers.
+"""
+from __future__ import annotations
+
+import random
+from typing import List, Sequence, Tuple
+
+from dsp_amd.schema import Col
+
+# ---------------------------------------------------------------------------- schemas
+
+SMALL = [
+    Col("a", "char", 5),
+    Col("b", "number", 22),
+    Col("c", "date", 14),
+    Col("ab", "char", 0),
+    Col("n", "number", 6),
+]
+
+# names that collide in their first eight bytes, a name of the maximum length (31) and a
+# one-letter name
+LONGNAMES = [
+    Col("ddatetime", "date", 14),
+    Col("ddatetim2", "char", 8),
+    Col("ddatetime_ext", "number", 22),
+    Col("x" * 31, "char", 40),
+    Col("x" * 30, "char", 3),
+    Col("t", "number", 22),
+]
+
+# duplicate column names and a name that is another one's close tag
+ODD = [
+    Col("a", "char", 4),
+    Col("a", "number", 22),
+    Col("/a", "char", 0),
+    Col("", "char", 3),
+    Col("endl/", "char", 10),
+]
+
+
+# ---------------------------------------------------------------------------- probes
+
+def probe_xml() -> List[Tuple[str, bytes, Sequence[Col], str]]:
+    """(name, input, schema, endbz) known-answer style inputs."""
+    E = b"<endl/>\n"
+    out = []
+    add = lambda name, data, cols=SMALL, endbz="<endl/>": out.append((name, data, cols, endbz))
+    add("empty", b"")
+    add("only_newline", b"\n")
+    add("only_terminator", E)
+    add("two_empty_records", E + E)
+    add("no_terminator", b"<a>1</a><endl/>")
+    add("crlf_not_terminator", b"<a>1</a><endl/>\r\n<a>2</a>" + E)
+    add("midline_endl", b"<a>1</a><endl/><a>2</a>" + E)
+    add("tail_dropped", b"<a>1</a>" + E + b"<a>2</a><endl/>")
+    add("data_framing", b"<data>\n<a>1</a><b>2</b>" + E + b"<a>3</a>" + E + b"</data>\n")
+    add("interior_newlines", b"<a>x\ny</a>\n\n<b>1\n2</b>" + E)
+    add("close_before_open", b"</a>zz<a>hello</a>tail" + E)
+    add("close_before_open_num", b"</b>zz<b>12x.5</b>t-9" + E)
+    add("prefix_name_no_match", b"<ab>long</ab>" + E)
+    add("tag_inside_value", b"<ab>..<a>in</a>..</ab>" + E)
+    add("duplicate_first_wins", b"<a>one</a><a>two</a>" + E)
+    add("nested", b"<a><a>1</a></a>" + E)
+    add("case_sensitive", b"<A>1</A><a>2</a>" + E)
+    add("clip_char", b"<a>abcdefghij</a>" + E)
+    add("clip_then_filter_date", b"<c>2024-05-19 16:28:00</c>" + E)
+    add("number_filter", b"<b> -12.5e3 hPa+</b>" + E)
+    add("carry_forward", b"<a>xy9</a><b>10000.5</b>" + E)            # c, ab, n missing
+    add("carry_first_missing", b"<b>7</b>" + E)
+    add("carry_restrictive_then_char", b"<b>1.5</b><ab>zz</ab>" + E)  # c missing -> "15"
+    add("open_only", b"<a>1<b>2</b>" + E)
+    add("close_only", b"1</a><b>2</b>" + E)
+    add("nul_in_value", b"<a>x\x00y</a><b>1\x002</b><ab>q\x00r5</ab>" + E)
+    add("nul_then_carry", b"<ab>ab\x00cd12</ab>" + E, [Col("ab", "char", 0), Col("z", "number", 22)])
+    add("utf8_clip", "<a>观测站点</a>".encode() + E)
+    add("high_bytes_digits", b"<b>\xff1\x802\xb9</b>" + E)
+    add("empty_value", b"<a></a><b></b>" + E)
+    add("overlap_tags", b"<a><b>1</a>2</b>" + E)
+    add("endl_in_value", b"<a><endl/></a>" + E)
+    add("lt_gt_noise", b"<<a>>1<</a>><b><>2</b>" + E)
+    add("first_record_prefix", b"<?xml version='1.0'?>\n<!--c-->\n<x>\n  <a>1</a>" + E + b"</x>\n")
+    add("lines_mode", b"l1\n\nl3\r\nlast", SMALL, "")
+    add("custom_endbz", b"<a>1</a>;;\n<a>2</a>;\n;;\n", SMALL, ";;")
+    add("long_endbz", b"<a>1</a>0123456789abcdef\n<a>2</a>123456789abcdef\n", SMALL, "0123456789abcdef")
+    add("longnames", b"<ddatetime>2024-01-02</ddatetime><ddatetim2>abcdefghijk</ddatetim2>"
+        b"<ddatetime_ext>-1.5</ddatetime_ext><" + b"x" * 31 + b">full</" + b"x" * 31 + b"><"
+        + b"x" * 30 + b">short</" + b"x" * 30 + b"><t>3</t>" + E, LONGNAMES)
+    add("longnames_nearmiss", b"<ddatetimX>1</ddatetimX><ddatetime_exu>2</ddatetime_exu><"
+        + b"x" * 32 + b">3</" + b"x" * 32 + b">" + E, LONGNAMES)
+    add("odd_schema", b"<a>12ab</a></a>s<>e</></endl/>f<endl/>g" + E, ODD)
+    add("odd_schema2", b"</a>q</a><a>7</a><//a>" + E, ODD)
+    # the reference's own sample lines (public/_public.h:131-132)
+    add("public_h_sample",
+        b"<filename>/tmp/_public.h</filename><mtime>2020-01-01 12:20:35</mtime><size>18348</size>\n"
+        b"<filename>/tmp/_public.cpp</filename><mtime>2020-01-01 10:10:15</mtime><size>50945</size>\n",
+        [Col("filename", "char", 300), Col("mtime", "date", 14), Col("size", "number", 22)], "")
+    return out
+
+
+INI_XMLTODB = (
+    # byte-for-byte the structure of the reference's idc/ini/xmltodb.xml (2 records, the
+    # second without <execsql>); the comment text is replaced by ASCII
+    b"<?xml version='1.0' encoding='utf-8'?>\n\n<!--ingest parameters-->\n<xmltodb>\n"
+    b"  <filename>ZHOBTCODE_*.XML</filename><tname>T_ZHOBTCODE1</tname><uptbz>1</uptbz>"
+    b"<execsql>delete from T_ZHOBTCODE1</execsql><endl/>\n"
+    b"  <filename>ZHOBTMIND_*.XML</filename><tname>T_ZHOBTMIND1</tname><uptbz>1</uptbz><endl/>\n"
+    b"</xmltodb>"
+)
+INI_COLS = [Col("filename", "char", 0), Col("tname", "char", 0), Col("uptbz", "char", 0),
+            Col("execsql", "char", 0)]
+
+
+def probe_convert() -> List[bytes]:
+    return [
+        b"", b"0", b"12.7", b"5-3", b"-", b"+", b"+-5", b"-5", b"--5", b"2147483647", b"2147483648",
+        b"-2147483648", b"-2147483649", b"4000000000", b"9223372036854775807",
+        b"9223372036854775808", b"-9223372036854775808", b"-9223372036854775809",
+        b"18446744073709551615", b"18446744073709551616", b"1.2.3", b".", b".5", b"-.5", b"5.",
+        b"1e5", b"0.1", b"0.3", b"123456789012345678", b"1234567890123456789012",
+        b"9007199254740993", b"9007199254740992.5", b"9007199254740993.0000000001",
+        b"0.1000000000000000055511151231257827", b"179769313486231580793728971405303415079934132710037826936173778980444968292764750946649017977587207096330286416692887910946555547851940402630657488671505820681908902000708383676273854845817711531764475730270069855571366959622842914819860834936475292719074168444365510704342711559699508093042880177904174497791",
+        b"1" + b"0" * 400, b"0." + b"0" * 400 + b"1", b"0." + b"0" * 320 + b"1",
+        b"2.2250738585072011e-308", b"0.000000000000000000000000000000000000011754943508222875",
+        b"340282350000000000000000000000000000000", b"340282356779733661637539395458142568448",
+        b"16777217", b"16777216.5", b"0.1000000014901161", b"1.00000017881393421514957253748434595763683319091796875",
+        b"TRUE", b"true", b"True", b" true", b"TRUEx", b"false", b"00012", b"-0", b"-0.0", b"+.0",
+        b" -12.5e3 hPa+", b"1,234.5", b"12abc34", b"\xff9\x008", b"99999999999999999999.99",
+        b"4.35", b"0.000001", b"123456.789e3", b"8.5", b"1013.2", b"10000.5",
+    ]
+
+
+def probe_trim() -> List[bytes]:
+    return [b"", b" ", b"   ", b"a", b" a", b"a ", b" a ", b"  ab  ", b"a,", b",a,", b" x ", b" b ",
+            b"x  y", b"  x  y  ", b"\t a \t"]
+
+
+# ---------------------------------------------------------------------------- random XML
+
+_VALUES = [b"", b"0", b"1", b"-1", b"12.7", b"1013.2", b"-40.0", b"+5", b"1e5", b"1.2.3", b"..", b"-",
+           b"2024-05-19 16:28:00", b"20240519162800", b"abc", b"hello world", b" 42 ", b"4.35",
+           b"99999999999999999999999999", b"123456789012345678901234567890.5", b"x\x00y", b"\xe8\xa7\x82",
+           b"<", b">", b"</", b"a<b", b"\r", b"\n", b"0.000001", b"9007199254740993"]
+
+
+def _rand_value(rng: random.Random) -> bytes:
+    k = rng.random()
+    if k < 0.45:
+        return rng.choice(_VALUES)
+    if k < 0.75:
+        n = rng.randrange(0, 30)
+        return bytes(rng.choice(b"0123456789+-. eE") for _ in range(n))
+    n = rng.randrange(0, 60)
+    return bytes(rng.choice(b"abcXYZ019 .-+<>/\n\r\x00\xe8\xa7\x82") for _ in range(n))
+
+
+def mutated_xml(seed: int, nrec: int, cols: Sequence[Col], endbz: str = "<endl/>",
+                damage: float = 0.3) -> bytes:
+    """Records built from the schema with random damage (missing/duplicated/reordered/nested
+    tags, near-miss names, long values, odd terminators)."""
+    rng = random.Random(seed)
+    names = [c.colname.encode() for c in cols]
+    out = bytearray()
+    if rng.random() < 0.5:
+        out += b"<data>\n"
+    term = endbz.encode() + b"\n"
+    for _ in range(nrec):
+        order = list(range(len(cols)))
+        if rng.random() < damage:
+            rng.shuffle(order)
+        for i in order:
+            nm = names[i]
+            r = rng.random()
+            if r < damage * 0.3:
+                continue                                   # missing tag
+            v = _rand_value(rng)
+            if r < damage * 0.4:
+                out += b"</" + nm + b">" + v + b"<" + nm + b">" + _rand_value(rng) + b"</" + nm + b">"
+            elif r < damage * 0.5:
+                out += b"<" + nm + b">" + v                  # open only
+            elif r < damage * 0.6:
+                out += v + b"</" + nm + b">"                 # close only
+            elif r < damage * 0.7:
+                out += b"<" + nm + b"x>" + v + b"</" + nm + b"x>"   # near miss
+            elif r < damage * 0.8:
+                out += b"<" + nm + b"><" + nm + b">" + v + b"</" + nm + b"></" + nm + b">"
+            elif r < damage * 0.9:
+                out += b"<" + nm.upper() + b">" + v + b"</" + nm.upper() + b">"
+            else:
+                out += b"<" + nm + b">" + v + b"</" + nm + b">"
+            if rng.random() < damage * 0.1:
+                out += b"\n"
+        r = rng.random()
+        if r < damage * 0.1:
+            out += endbz.encode() + b"\r\n"
+        elif r < damage * 0.2:
+            out += endbz.encode() + b" \n"
+        elif r < damage * 0.25:
+            out += endbz.encode()
+        else:
+            out += term
+    r = rng.random()
+    if r < 0.4:
+        out += b"</data>\n"
+    elif r < 0.6:
+        out += b"<" + names[0] + b">tail</" + names[0] + b">" + endbz.encode()
+    return bytes(out)
+
+
+def soup_xml(seed: int, ntok: int, cols: Sequence[Col], endbz: str = "<endl/>") -> bytes:
+    """Unstructured token soup over the schema's tags and delimiters."""
+    rng = random.Random(seed)
+    toks = [b"<", b">", b"/", b"\n", b"\r", b"\x00", b" ", b"<endl/>", b"<endl/>\n", endbz.encode() + b"\n",
+            b"0", b"1", b"9", b".", b"-", b"+", b"x", b"<data>\n", b"</data>\n", b"\xe8\xa7\x82"]
+    for c in cols:
+        nm = c.colname.encode()
+        toks += [b"<" + nm + b">", b"</" + nm + b">", b"<" + nm, nm + b">", b"<" + nm + b">" + b"5" * 3 + b"</" + nm + b">"]
+    return b"".join(rng.choice(toks) for _ in range(ntok))
+
+
+# ---------------------------------------------------------------------------- random CSV
+
+def fuzz_csv(seed: int, nlines: int, sep: str, nfields: int) -> bytes:
+    rng = random.Random(seed)
+    s = sep.encode()
+    vals = [b"", b" ", b"  x  ", b"12.7", b"-5", b"+3", b"1e5", b"TRUE", b"true", b" true", b"58015",
+            b"20240519162800", b"1013.2", b"0.0", b"10000.5", b"1234567", b"a,", b"a b", b" b ",
+            b"99999999999999999999", b"4000000000", b"\r", b"x\x00y", b"1.2.3", b"~", b"!", b"~!"]
+    out = bytearray()
+    for _ in range(nlines):
+        k = rng.choice([0, 1, nfields - 1, nfields, nfields, nfields, nfields + 1, nfields + 3])
+        fields = []
+        for _ in range(k):
+            if rng.random() < 0.6:
+                fields.append(rng.choice(vals))
+            else:
+                fields.append(bytes(rng.choice(b"0123456789.-+ abT") for _ in range(rng.randrange(0, 12))))
+        line = s.join(fields)
+        if rng.random() < 0.1:
+            line += s
+        if rng.random() < 0.05:
+            line += s[:1]
+        out += line + b"\n"
+    if rng.random() < 0.5:
+        out += b"unterminated" + s + b"tail"
+    return bytes(out)
+
+
+def probe_csv() -> List[Tuple[str, bytes, str, bool]]:
+    return [
+        ("messi", b"messi,10,striker,30,1.72,68.5,Barcelona\n", ",", False),
+        ("multi_sep", b"x~!~y~!~!~z\n", "~!~", False),
+        ("empty_line", b"\n\n", ",", False),
+        ("trailing_sep", b"a,b,\n", ",", False),
+        ("delspace_bug", b" x , a ,b , c\n", ",", True),
+        ("only_seps", b",,,\n", ",", False),
+        ("crlf", b"1,2\r\n3,4\r\n", ",", False),
+        ("mind_row", b"58015,20240519162800,12.7,1013.2,65,180,3.4,0.0,10000.5,1234567\n", ",", False),
+        ("unterminated_tail", b"1,2\n3,4", ",", False),
+        ("space_sep", b"a  b c\n", " ", False),
+    ]
