@@ -1,0 +1,318 @@
+"""ctypes binding of libmdc_parse.so (include/mdc_parse.h).
+
+Used by the tests, bench.py and the examples; everything goes through the C ABI, exactly as a
+C/C++ caller would.  There is no Python or CPU implementation of the parsing path here: if the
+shared library is missing, or no GPU is usable, calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .schema import CCol, Col, c_cols
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdc_parse.so")
+
+MDC_OK = 0
+MDC_FILE_OPEN_FAILED = 5
+MDC_ERR_ARG = -1
+MDC_ERR_NO_DEVICE = -2
+MDC_ERR_HIP = -3
+MDC_ERR_NOMEM = -4
+MDC_ERR_RECORD_TOO_LONG = -5
+MDC_ERR_TOO_LARGE = -6
+MDC_ERR_NUMERIC = -7
+MDC_ERR_IO = -8
+MDC_ERR_INTERNAL = -9
+MDC_F_NO_RECOFF = 1
+
+# every symbol include/mdc_parse.h declares
+EXPORTS = [
+    "mdc_version", "mdc_device_count", "mdc_strerror", "mdc_last_error",
+    "mdc_parser_create_xml", "mdc_parser_create_csv", "mdc_parser_destroy",
+    "mdc_parse_device", "mdc_parse_host", "mdc_parse_file", "mdc_parser_last_timing",
+    "mdc_parse_xml_buffer", "mdc_parse_xml_file", "mdc_parse_csv_buffer",
+    "mdc_batch_rows", "mdc_batch_ncols", "mdc_batch_words_per_row",
+    "mdc_batch_device_column", "mdc_batch_device_values", "mdc_batch_device_masks", "mdc_batch_device_recoff",
+    "mdc_batch_host_column", "mdc_batch_host_values", "mdc_batch_host_masks", "mdc_batch_host_recoff",
+    "mdc_batch_cell", "mdc_batch_column_fixed", "mdc_batch_free",
+    "mdc_device_alloc", "mdc_device_free", "mdc_device_upload", "mdc_device_download",
+    "mdc_device_synchronize",
+]
+
+
+class MdcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"mdc error {code}: {msg}")
+        self.code = code
+
+
+class COpts(ctypes.Structure):
+    _fields_ = [
+        ("device", ctypes.c_int),
+        ("endbz", ctypes.c_char_p),
+        ("carry", ctypes.c_int),
+        ("typed", ctypes.POINTER(ctypes.c_int)),
+        ("flags", ctypes.c_uint),
+    ]
+
+
+class CTiming(ctypes.Structure):
+    _fields_ = [
+        ("count_ms", ctypes.c_float),
+        ("scan_ms", ctypes.c_float),
+        ("write_ms", ctypes.c_float),
+        ("total_ms", ctypes.c_float),
+        ("bytes_in", ctypes.c_uint64),
+        ("bytes_out", ctypes.c_uint64),
+        ("rows", ctypes.c_int64),
+        ("tiles", ctypes.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libmdc_parse.so; raises if it has not been built (there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m dsp_amd.build` "
+                               "(the parsing path exists only as gfx950 code)")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, sz, ci, i64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int64
+        pp = ctypes.POINTER(vp)
+        L.mdc_version.restype = ctypes.c_char_p
+        L.mdc_strerror.restype = ctypes.c_char_p
+        L.mdc_strerror.argtypes = [ci]
+        L.mdc_last_error.restype = ctypes.c_char_p
+        L.mdc_device_count.restype = ci
+        L.mdc_parser_create_xml.argtypes = [vp, ci, ctypes.POINTER(COpts), pp]
+        L.mdc_parser_create_csv.argtypes = [ctypes.c_char_p, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(COpts), pp]
+        L.mdc_parser_destroy.argtypes = [vp]
+        L.mdc_parser_destroy.restype = None
+        L.mdc_parse_device.argtypes = [vp, vp, sz, pp]
+        L.mdc_parse_host.argtypes = [vp, vp, sz, pp]
+        L.mdc_parse_file.argtypes = [vp, ctypes.c_char_p, pp]
+        L.mdc_parser_last_timing.argtypes = [vp, ctypes.POINTER(CTiming)]
+        L.mdc_parse_xml_buffer.argtypes = [vp, sz, vp, ci, ctypes.POINTER(COpts), pp]
+        L.mdc_parse_xml_file.argtypes = [ctypes.c_char_p, vp, ci, ctypes.POINTER(COpts), pp]
+        L.mdc_parse_csv_buffer.argtypes = [vp, sz, ctypes.c_char_p, ci, ci, ctypes.POINTER(ci),
+                                           ctypes.POINTER(COpts), pp]
+        L.mdc_batch_rows.restype = i64
+        L.mdc_batch_rows.argtypes = [vp]
+        L.mdc_batch_ncols.argtypes = [vp]
+        L.mdc_batch_words_per_row.argtypes = [vp]
+        L.mdc_batch_device_column.argtypes = [vp, ci, pp, pp, ctypes.POINTER(ctypes.c_uint64)]
+        L.mdc_batch_device_values.argtypes = [vp, ci, pp]
+        L.mdc_batch_device_masks.argtypes = [vp, pp, pp]
+        L.mdc_batch_device_recoff.argtypes = [vp, pp]
+        L.mdc_batch_host_column.argtypes = [vp, ci, pp, pp, ctypes.POINTER(ctypes.c_uint64)]
+        L.mdc_batch_host_values.argtypes = [vp, ci, pp]
+        L.mdc_batch_host_masks.argtypes = [vp, pp, pp]
+        L.mdc_batch_host_recoff.argtypes = [vp, pp]
+        L.mdc_batch_cell.argtypes = [vp, i64, ci, pp, ctypes.POINTER(ctypes.c_uint32)]
+        L.mdc_batch_column_fixed.argtypes = [vp, ci, pp, ctypes.POINTER(sz)]
+        L.mdc_batch_free.argtypes = [vp]
+        L.mdc_batch_free.restype = None
+        L.mdc_device_alloc.argtypes = [ci, sz, pp]
+        L.mdc_device_free.argtypes = [ci, vp]
+        L.mdc_device_upload.argtypes = [ci, vp, vp, sz]
+        L.mdc_device_download.argtypes = [ci, vp, vp, sz]
+        L.mdc_device_synchronize.argtypes = [ci]
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != MDC_OK:
+        raise MdcError(rc, lib().mdc_last_error().decode(errors="replace"))
+
+
+def _np_from(ptr, count, dtype):
+    if count == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (ctypes.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+
+@dataclass
+class HostColumns:
+    """Host copy of a batch (same fields as the CPU checker's result, so tests can compare)."""
+
+    rows: int
+    ncols: int
+    rec_off: Optional[np.ndarray]
+    off: List[np.ndarray]
+    data: List[np.ndarray]
+    val: List[Optional[np.ndarray]]
+    valid: np.ndarray
+    found: np.ndarray
+
+    def cell(self, row: int, col: int) -> bytes:
+        o = self.off[col]
+        return bytes(self.data[col][int(o[row]):int(o[row + 1])])
+
+
+class Batch:
+    def __init__(self, handle: int):
+        self.h = ctypes.c_void_p(handle)
+
+    def __del__(self):
+        self.free()
+
+    def free(self):
+        if self.h:
+            lib().mdc_batch_free(self.h)
+            self.h = None
+
+    @property
+    def rows(self) -> int:
+        return int(lib().mdc_batch_rows(self.h))
+
+    @property
+    def ncols(self) -> int:
+        return int(lib().mdc_batch_ncols(self.h))
+
+    @property
+    def words(self) -> int:
+        return int(lib().mdc_batch_words_per_row(self.h))
+
+    def column(self, col: int):
+        off, data, nb = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+        check(lib().mdc_batch_host_column(self.h, col, ctypes.byref(off), ctypes.byref(data), ctypes.byref(nb)))
+        return _np_from(off.value, self.rows + 1, np.uint32), _np_from(data.value, nb.value, np.uint8)
+
+    def values(self, col: int) -> Optional[np.ndarray]:
+        v = ctypes.c_void_p()
+        rc = lib().mdc_batch_host_values(self.h, col, ctypes.byref(v))
+        if rc == MDC_ERR_ARG:
+            return None
+        check(rc)
+        return _np_from(v.value, self.rows, np.uint64)
+
+    def masks(self):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        check(lib().mdc_batch_host_masks(self.h, ctypes.byref(a), ctypes.byref(b)))
+        w = self.words
+        return (_np_from(a.value, self.rows * w, np.uint32).reshape(self.rows, w),
+                _np_from(b.value, self.rows * w, np.uint32).reshape(self.rows, w))
+
+    def rec_off(self) -> Optional[np.ndarray]:
+        p = ctypes.c_void_p()
+        rc = lib().mdc_batch_host_recoff(self.h, ctypes.byref(p))
+        if rc == MDC_ERR_ARG:
+            return None
+        check(rc)
+        return _np_from(p.value, self.rows + 1, np.uint64)
+
+    def cell(self, row: int, col: int) -> bytes:
+        p, n = ctypes.c_void_p(), ctypes.c_uint32()
+        check(lib().mdc_batch_cell(self.h, row, col, ctypes.byref(p), ctypes.byref(n)))
+        return ctypes.string_at(p.value, n.value) if n.value else b""
+
+    def column_fixed(self, col: int):
+        p, st = ctypes.c_void_p(), ctypes.c_size_t()
+        check(lib().mdc_batch_column_fixed(self.h, col, ctypes.byref(p), ctypes.byref(st)))
+        return _np_from(p.value, self.rows * st.value, np.uint8).reshape(self.rows, st.value), st.value
+
+    def device_column(self, col: int):
+        off, data, nb = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+        check(lib().mdc_batch_device_column(self.h, col, ctypes.byref(off), ctypes.byref(data), ctypes.byref(nb)))
+        return off.value, data.value, nb.value
+
+    def to_host(self) -> HostColumns:
+        cols = [self.column(c) for c in range(self.ncols)]
+        valid, found = self.masks()
+        return HostColumns(self.rows, self.ncols, self.rec_off(), [c[0] for c in cols], [c[1] for c in cols],
+                           [self.values(c) for c in range(self.ncols)], valid, found)
+
+
+class Parser:
+    """A schema bound to one GPU (mdc_parser)."""
+
+    def __init__(self, handle, device: int, keep):
+        self.h = handle
+        self.device = device
+        self._keep = keep
+
+    @classmethod
+    def xml(cls, cols: Sequence[Col], typed: Optional[Sequence[int]] = None, endbz: Optional[str] = "<endl/>",
+            carry: bool = True, device: int = 0, flags: int = 0) -> "Parser":
+        cc = c_cols(cols)
+        ty = (ctypes.c_int * len(cols))(*typed) if typed is not None else None
+        opts = COpts(device, endbz.encode() if endbz is not None else None, int(carry),
+                     ctypes.cast(ty, ctypes.POINTER(ctypes.c_int)) if ty is not None else None, flags)
+        h = ctypes.c_void_p()
+        check(lib().mdc_parser_create_xml(cc, len(cols), ctypes.byref(opts), ctypes.byref(h)))
+        return cls(h, device, (cc, ty, opts))
+
+    @classmethod
+    def csv(cls, sep: str, nfields: int, ilen: Optional[Sequence[int]] = None,
+            typed: Optional[Sequence[int]] = None, bdelspace: bool = False, device: int = 0,
+            flags: int = 0) -> "Parser":
+        il = (ctypes.c_int * nfields)(*ilen) if ilen is not None else None
+        ty = (ctypes.c_int * nfields)(*typed) if typed is not None else None
+        opts = COpts(device, None, 0, ctypes.cast(ty, ctypes.POINTER(ctypes.c_int)) if ty is not None else None, flags)
+        h = ctypes.c_void_p()
+        check(lib().mdc_parser_create_csv(sep.encode(), int(bdelspace), nfields,
+                                          ctypes.cast(il, ctypes.POINTER(ctypes.c_int)) if il is not None else None,
+                                          ctypes.byref(opts), ctypes.byref(h)))
+        return cls(h, device, (il, ty, opts))
+
+    def close(self):
+        if self.h:
+            lib().mdc_parser_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def parse_host(self, data) -> Batch:
+        buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data)
+        h = ctypes.c_void_p()
+        check(lib().mdc_parse_host(self.h, buf.ctypes.data if buf.size else None, buf.size, ctypes.byref(h)))
+        return Batch(h.value)
+
+    def parse_device(self, d_ptr: int, n: int) -> Batch:
+        h = ctypes.c_void_p()
+        check(lib().mdc_parse_device(self.h, d_ptr, n, ctypes.byref(h)))
+        return Batch(h.value)
+
+    def parse_file(self, path: str) -> Batch:
+        h = ctypes.c_void_p()
+        check(lib().mdc_parse_file(self.h, path.encode(), ctypes.byref(h)))
+        return Batch(h.value)
+
+    def timing(self) -> CTiming:
+        t = CTiming()
+        check(lib().mdc_parser_last_timing(self.h, ctypes.byref(t)))
+        return t
+
+
+class DeviceBuffer:
+    """Input bytes resident in HBM (mdc_device_alloc / upload)."""
+
+    def __init__(self, data: np.ndarray, device: int = 0):
+        self.device = device
+        self.n = int(data.size)
+        p = ctypes.c_void_p()
+        check(lib().mdc_device_alloc(device, max(self.n, 1), ctypes.byref(p)))
+        self.ptr = p.value
+        if self.n:
+            data = np.ascontiguousarray(data)
+            check(lib().mdc_device_upload(device, self.ptr, data.ctypes.data, self.n))
+
+    def free(self):
+        if self.ptr:
+            lib().mdc_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.free()

@@ -1,0 +1,885 @@
+// mdc_abi.cpp -- host side of libmdc_parse.so: the C ABI declared in include/mdc_parse.h.
+//
+// Holds no parsing logic: it validates arguments, turns a schema into the blob the kernels
+// read (column descriptors + tag hash table), sizes LDS regions and output buffers, launches
+// the gfx950 kernels of mdc_kernels.hip and mirrors results to the host on request.  There is
+// no CPU implementation of the path here: without a usable HIP device every parse call fails
+// with MDC_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "mdc_device.h"
+#include "mdc_parse.h"
+
+namespace mdc {
+hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t stream);
+hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt,
+                             hipStream_t stream);
+hipError_t launch_fixed_stride(const uint32_t *off, const uint8_t *bytes, uint8_t *slab, uint64_t rows,
+                               uint32_t stride, hipStream_t stream);
+}  // namespace mdc
+
+using namespace mdc;
+
+// ------------------------------------------------------------------------------------------
+// errors
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(MDC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// devices and a caching device allocator (hipMalloc of GB-sized buffers costs milliseconds;
+// a daemon parses file after file of the same shape)
+
+struct Device {
+    int id = -1;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;
+    std::map<void *, size_t> live;
+};
+
+static std::mutex g_dev_mu;
+static std::map<int, Device *> g_devices;
+
+static int get_device(int id, Device **out) {
+    if (id < 0) id = 0;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto it = g_devices.find(id);
+    if (it != g_devices.end()) {
+        *out = it->second;
+        return MDC_OK;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(MDC_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (id >= count) return fail(MDC_ERR_ARG, "device %d out of range (%d devices)", id, count);
+    HIP_TRY(hipSetDevice(id));
+    Device *d = new Device();
+    d->id = id;
+    HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    g_devices[id] = d;
+    *out = d;
+    return MDC_OK;
+}
+
+static size_t size_class(size_t n) {
+    if (n < 4096) return 4096;
+    // round up to 1/8 steps of the enclosing power of two
+    size_t p = 1;
+    while (p < n) p <<= 1;
+    size_t step = p / 16;
+    return (n + step - 1) / step * step;
+}
+
+static int dev_alloc(Device *d, size_t n, void **out) {
+    size_t want = size_class(n ? n : 1);
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        auto it = d->free_blocks.lower_bound(want);
+        if (it != d->free_blocks.end() && it->first <= want + want / 4 + 65536) {
+            *out = it->second;
+            d->live[it->second] = it->first;
+            d->free_blocks.erase(it);
+            return MDC_OK;
+        }
+    }
+    HIP_TRY(hipSetDevice(d->id));
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        std::lock_guard<std::mutex> lk(d->mu);
+        for (auto &kv : d->free_blocks) (void)hipFree(kv.second);
+        d->free_blocks.clear();
+        e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(MDC_ERR_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lk(d->mu);
+    d->live[p] = want;
+    *out = p;
+    return MDC_OK;
+}
+
+static void dev_free(Device *d, void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(d->mu);
+    auto it = d->live.find(p);
+    if (it == d->live.end()) return;
+    d->free_blocks.emplace(it->second, p);
+    d->live.erase(it);
+}
+
+// ------------------------------------------------------------------------------------------
+// parser
+
+struct mdc_parser {
+    Device *dev = nullptr;
+    uint32_t mode = MODE_XML;
+    int ncols = 0;
+    uint32_t words = 1;
+    unsigned flags = 0;
+    std::vector<mdc_col> cols;
+    std::vector<int> typed;
+    std::vector<uint8_t> blob;
+    void *d_blob = nullptr;
+    LdsLayout L{};
+    // workspace
+    uint32_t *d_counts = nullptr;
+    uint64_t *d_base = nullptr;
+    uint32_t *d_status = nullptr;
+    size_t ws_tiles = 0;
+    uint64_t *h_totals = nullptr;  // pinned: ncols+1 totals + status
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    mdc_timing timing{};
+};
+
+struct mdc_batch {
+    Device *dev = nullptr;
+    int64_t rows = 0;
+    int ncols = 0;
+    uint32_t words = 1;
+    std::vector<int> typed;
+    std::vector<int> collen;
+    uint64_t *d_rec_off = nullptr;
+    std::vector<uint32_t *> d_off;
+    std::vector<uint8_t *> d_bytes;
+    std::vector<uint64_t> nbytes;
+    std::vector<uint64_t *> d_val;
+    uint32_t *d_valid = nullptr, *d_found = nullptr;
+    void *d_ptrs = nullptr;  // device arrays of the column pointers
+    // host mirrors
+    std::vector<uint64_t> h_rec_off;
+    std::vector<std::vector<uint32_t>> h_off;
+    std::vector<std::vector<uint8_t>> h_bytes;
+    std::vector<std::vector<uint64_t>> h_val;
+    std::vector<uint32_t> h_valid, h_found;
+    std::vector<bool> have_col, have_val;
+    bool have_masks = false, have_recoff = false;
+    std::vector<std::vector<char>> h_fixed;
+    std::vector<size_t> fixed_stride;
+};
+
+static uint32_t round16(uint32_t v) { return (v + 15) & ~15u; }
+
+static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32_t blob_bytes, LdsLayout &L) {
+    uint32_t RB = 128;
+    for (;;) {
+        uint32_t o = 0;
+        L.data = o;
+        o += round16(TILE + LBMAX + DATA_SLACK);
+        L.evt = o;
+        o += round16(RB * (npat > ncols ? npat : ncols) * 4);
+        L.dstart = o;
+        o += round16(RB * ncols * 4);
+        L.dlen = o;
+        o += round16(RB * ncols * 4);
+        L.cterm = o;
+        o += round16(NCH * 2);
+        L.cpre = o;
+        o += round16(NCH * 2);
+        L.recend = o;
+        o += round16((RB + 1) * 4);
+        L.vmask = o;
+        o += round16(RB * words * 4);
+        L.fmask = o;
+        o += round16(RB * words * 4);
+        L.coltot = o;
+        o += round16(3 * (ncols + 1) * 4);
+        L.schema = o;
+        o += round16(blob_bytes);
+        L.misc = o;
+        o += 256;
+        L.stage = o;
+        uint32_t stage_cap = 8192;
+        o += stage_cap;
+        L.stage_cap = stage_cap;
+        L.total = o;
+        L.RB = RB;
+        if (o <= 80 * 1024 || RB <= 8) break;
+        RB /= 2;
+    }
+}
+
+static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *sep, int bdelspace) {
+    const uint32_t ncols = (uint32_t)p->ncols;
+    const uint32_t npat = p->mode == MODE_XML ? 2 * ncols : 0;
+    uint32_t ht_size = 16;
+    while (ht_size < 4 * npat) ht_size <<= 1;
+    const size_t cols_bytes = (ncols * sizeof(DevCol) + 15) & ~(size_t)15;
+    p->blob.assign(sizeof(SchemaHdr) + cols_bytes + ht_size * sizeof(HtEntry), 0);
+    SchemaHdr *H = (SchemaHdr *)p->blob.data();
+    DevCol *dc = (DevCol *)(H + 1);
+    HtEntry *ht = (HtEntry *)((uint8_t *)dc + cols_bytes);
+    H->ncols = ncols;
+    H->npat = npat;
+    H->ht_mask = ht_size - 1;
+    H->carry = carry ? 1 : 0;
+    H->mode = p->mode;
+    H->words = p->words;
+    H->bdelspace = bdelspace ? 1 : 0;
+    size_t el = strlen(endbz);
+    if (el > MAX_ENDBZ) return fail(MDC_ERR_ARG, "endbz longer than %d bytes", MAX_ENDBZ);
+    if (memchr(endbz, '\n', el)) return fail(MDC_ERR_ARG, "endbz must not contain a newline");
+    H->endbz_len = (uint32_t)el;
+    memcpy(H->endbz, endbz, el);
+    if (p->mode == MODE_CSV) {
+        size_t sl = strlen(sep);
+        if (sl == 0 || sl > MAX_SEP) return fail(MDC_ERR_ARG, "separator must be 1..%d bytes", MAX_SEP);
+        if (memchr(sep, '\n', sl)) return fail(MDC_ERR_ARG, "separator must not contain a newline");
+        H->sep_len = (uint32_t)sl;
+        memcpy(H->sep, sep, sl);
+    }
+    for (uint32_t c = 0; c < ncols; ++c) {
+        const mdc_col &col = p->cols[c];
+        size_t nl = strnlen(col.colname, 32);
+        if (nl > 31) return fail(MDC_ERR_ARG, "column %u: name not NUL-terminated", c);
+        if (memchr(col.colname, '>', nl) || memchr(col.colname, '\n', nl))
+            return fail(MDC_ERR_ARG, "column %u: name must not contain '>' or a newline", c);
+        memcpy(dc[c].name, col.colname, nl);
+        dc[c].namelen = (uint8_t)nl;
+        if (strcmp(col.datatype, "number") == 0)
+            dc[c].level = LVL_NUMBER;
+        else if (strcmp(col.datatype, "date") == 0)
+            dc[c].level = LVL_DATE;
+        else
+            dc[c].level = LVL_CHAR;  // splitbuffer leaves every other type untouched
+        int t = p->typed[c];
+        if (t == MDC_T_DEFAULT) t = dc[c].level == LVL_NUMBER ? MDC_T_F64 : dc[c].level == LVL_DATE ? MDC_T_I64 : MDC_T_NONE;
+        if (t < MDC_T_NONE || t > MDC_T_BOOL) return fail(MDC_ERR_ARG, "column %u: bad typed code %d", c, t);
+        p->typed[c] = t;
+        dc[c].typed = (uint8_t)t;
+        if (t != MDC_T_NONE) H->any_typed = 1;
+        dc[c].collen = col.collen;
+        if (p->mode != MODE_XML) continue;
+        for (uint32_t kind = 0; kind < 2; ++kind) {
+            uint8_t text[40];
+            uint32_t tlen = 0;
+            if (kind) text[tlen++] = '/';
+            memcpy(text + tlen, col.colname, nl);
+            tlen += (uint32_t)nl;
+            text[tlen] = '>';
+            uint8_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            memcpy(key, text, tlen + 1 < 8 ? tlen + 1 : 8);
+            uint32_t lo, hi;
+            memcpy(&lo, key, 4);
+            memcpy(&hi, key + 4, 4);
+            uint32_t slot = ht_hash(lo, hi) & H->ht_mask;
+            while (ht[slot].meta >> 31) slot = (slot + 1) & H->ht_mask;
+            ht[slot].klo = lo;
+            ht[slot].khi = hi;
+            ht[slot].meta = 0x80000000u | (c << 16) | (kind << 8) | tlen;
+        }
+    }
+    compute_layout(ncols, npat, p->words, (uint32_t)p->blob.size(), p->L);
+    if (p->L.total > 160 * 1024) return fail(MDC_ERR_ARG, "schema too large for LDS (%u bytes)", p->L.total);
+    return MDC_OK;
+}
+
+static int parser_finish(mdc_parser *p, const mdc_opts *opts) {
+    int rc = get_device(opts ? opts->device : -1, &p->dev);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(p->dev->id));
+    rc = dev_alloc(p->dev, p->blob.size(), &p->d_blob);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(p->d_blob, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
+    void *st = nullptr;
+    rc = dev_alloc(p->dev, 256, &st);
+    if (rc) return rc;
+    p->d_status = (uint32_t *)st;
+    HIP_TRY(hipHostMalloc((void **)&p->h_totals, (MAX_COLS + 8) * sizeof(uint64_t), hipHostMallocDefault));
+    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&p->ev[i]));
+    return MDC_OK;
+}
+
+extern "C" int mdc_parser_create_xml(const mdc_col *cols, int ncols, const mdc_opts *opts, mdc_parser **out) {
+    if (!out) return fail(MDC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (ncols < 1 || ncols > MAX_COLS || !cols) return fail(MDC_ERR_ARG, "ncols must be 1..%d", MAX_COLS);
+    mdc_parser *p = new mdc_parser();
+    p->mode = MODE_XML;
+    p->ncols = ncols;
+    p->words = (uint32_t)(ncols + 31) / 32;
+    p->flags = opts ? opts->flags : 0;
+    p->cols.assign(cols, cols + ncols);
+    p->typed.assign(ncols, MDC_T_DEFAULT);
+    if (opts && opts->typed) p->typed.assign(opts->typed, opts->typed + ncols);
+    const char *endbz = (opts && opts->endbz) ? opts->endbz : "<endl/>";
+    int carry = opts ? opts->carry : 1;
+    int rc = build_blob(p, endbz, carry, "", 0);
+    if (!rc) rc = parser_finish(p, opts);
+    if (rc) {
+        mdc_parser_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return MDC_OK;
+}
+
+extern "C" int mdc_parser_create_csv(const char *sep, int bdelspace, int nfields, const int *ilen,
+                                     const mdc_opts *opts, mdc_parser **out) {
+    if (!out) return fail(MDC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (nfields < 1 || nfields > MAX_COLS || !sep) return fail(MDC_ERR_ARG, "nfields must be 1..%d", MAX_COLS);
+    mdc_parser *p = new mdc_parser();
+    p->mode = MODE_CSV;
+    p->ncols = nfields;
+    p->words = (uint32_t)(nfields + 31) / 32;
+    p->flags = opts ? opts->flags : 0;
+    p->cols.resize(nfields);
+    for (int c = 0; c < nfields; ++c) {
+        memset(&p->cols[c], 0, sizeof(mdc_col));
+        snprintf(p->cols[c].colname, 32, "f%d", c);
+        strcpy(p->cols[c].datatype, "char");
+        p->cols[c].collen = ilen ? ilen[c] : 0;
+    }
+    p->typed.assign(nfields, MDC_T_NONE);
+    if (opts && opts->typed) p->typed.assign(opts->typed, opts->typed + nfields);
+    for (int c = 0; c < nfields; ++c)
+        if (p->typed[c] == MDC_T_DEFAULT) p->typed[c] = MDC_T_NONE;
+    const char *endbz = (opts && opts->endbz) ? opts->endbz : "";
+    int rc = build_blob(p, endbz, 0, sep, bdelspace);
+    if (!rc) rc = parser_finish(p, opts);
+    if (rc) {
+        mdc_parser_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return MDC_OK;
+}
+
+extern "C" void mdc_parser_destroy(mdc_parser *p) {
+    if (!p) return;
+    if (p->dev) {
+        (void)hipSetDevice(p->dev->id);
+        dev_free(p->dev, p->d_blob);
+        dev_free(p->dev, p->d_counts);
+        dev_free(p->dev, p->d_base);
+        dev_free(p->dev, p->d_status);
+        if (p->h_totals) (void)hipHostFree(p->h_totals);
+        for (int i = 0; i < 4; ++i)
+            if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
+    }
+    delete p;
+}
+
+// ------------------------------------------------------------------------------------------
+// parsing
+
+static void batch_release(mdc_batch *b) {
+    if (!b) return;
+    if (b->dev) {
+        dev_free(b->dev, b->d_rec_off);
+        for (auto q : b->d_off) dev_free(b->dev, q);
+        for (auto q : b->d_bytes) dev_free(b->dev, q);
+        for (auto q : b->d_val) dev_free(b->dev, q);
+        dev_free(b->dev, b->d_valid);
+        dev_free(b->dev, b->d_found);
+        dev_free(b->dev, b->d_ptrs);
+    }
+    delete b;
+}
+
+extern "C" void mdc_batch_free(mdc_batch *b) { batch_release(b); }
+
+static int ensure_workspace(mdc_parser *p, size_t ntiles) {
+    if (ntiles <= p->ws_tiles && p->d_counts) return MDC_OK;
+    dev_free(p->dev, p->d_counts);
+    dev_free(p->dev, p->d_base);
+    p->d_counts = nullptr;
+    p->d_base = nullptr;
+    size_t ncnt = (size_t)p->ncols + 1;
+    void *a = nullptr, *b = nullptr;
+    int rc = dev_alloc(p->dev, ntiles * ncnt * 4, &a);
+    if (rc) return rc;
+    rc = dev_alloc(p->dev, (ntiles + 1) * ncnt * 8, &b);
+    if (rc) {
+        dev_free(p->dev, a);
+        return rc;
+    }
+    p->d_counts = (uint32_t *)a;
+    p->d_base = (uint64_t *)b;
+    p->ws_tiles = ntiles;
+    return MDC_OK;
+}
+
+static int status_to_error(uint32_t st) {
+    if (st & ST_RECORD_TOO_LONG)
+        return fail(MDC_ERR_RECORD_TOO_LONG, "a record is longer than the %d-byte look-behind window", LBMAX);
+    if (st & ST_NUMERIC_RANGE)
+        return fail(MDC_ERR_NUMERIC,
+                    "a floating-point field has more than 38 significant or fractional digits");
+    if (st) return fail(MDC_ERR_INTERNAL, "kernel status %#x", st);
+    return MDC_OK;
+}
+
+extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc_batch **out) {
+    if (!p || !out) return fail(MDC_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    if (n && !d_data) return fail(MDC_ERR_ARG, "d_data is NULL");
+    if ((uintptr_t)d_data & 15) return fail(MDC_ERR_ARG, "d_data must be 16-byte aligned");
+    if (n >= ((size_t)1 << 40)) return fail(MDC_ERR_ARG, "input larger than 1 TiB");
+    Device *d = p->dev;
+    HIP_TRY(hipSetDevice(d->id));
+    const uint32_t ncols = (uint32_t)p->ncols, ncnt = ncols + 1;
+    const size_t ntiles = (n + TILE - 1) / TILE;
+    int rc = ensure_workspace(p, ntiles ? ntiles : 1);
+    if (rc) return rc;
+
+    TileParams P{};
+    P.data = (const uint8_t *)d_data;
+    P.n = n;
+    P.schema = (const uint8_t *)p->d_blob;
+    P.schema_bytes = (uint32_t)p->blob.size();
+    P.ntiles = (uint32_t)ntiles;
+    P.L = p->L;
+    P.tile_counts = p->d_counts;
+    P.tile_base = p->d_base;
+    P.status = p->d_status;
+
+    hipStream_t s = d->stream;
+    HIP_TRY(hipMemsetAsync(p->d_status, 0, 4, s));
+    HIP_TRY(hipEventRecord(p->ev[0], s));
+    HIP_TRY(launch_tile_kernel(false, P, s));
+    HIP_TRY(hipEventRecord(p->ev[1], s));
+    HIP_TRY(launch_scan_tiles(p->d_counts, p->d_base, (uint32_t)ntiles, ncnt, s));
+    HIP_TRY(hipEventRecord(p->ev[2], s));
+    HIP_TRY(hipMemcpyAsync(p->h_totals, p->d_base + ntiles * ncnt, ncnt * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(p->h_totals + ncnt, p->d_status, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    rc = status_to_error((uint32_t)p->h_totals[ncnt]);
+    if (rc) return rc;
+    mdc_timing &t = p->timing;
+    (void)hipEventElapsedTime(&t.count_ms, p->ev[0], p->ev[1]);
+    (void)hipEventElapsedTime(&t.scan_ms, p->ev[1], p->ev[2]);
+    const uint64_t rows = p->h_totals[ncols];
+    for (uint32_t c = 0; c < ncols; ++c)
+        if (p->h_totals[c] > 0xFFFFFFFFull)
+            return fail(MDC_ERR_TOO_LARGE, "column %u holds %llu bytes; split the input", c,
+                        (unsigned long long)p->h_totals[c]);
+
+    mdc_batch *b = new mdc_batch();
+    b->dev = d;
+    b->rows = (int64_t)rows;
+    b->ncols = (int)ncols;
+    b->words = p->words;
+    b->typed = p->typed;
+    for (auto &c : p->cols) b->collen.push_back(c.collen);
+    b->d_off.assign(ncols, nullptr);
+    b->d_bytes.assign(ncols, nullptr);
+    b->d_val.assign(ncols, nullptr);
+    b->nbytes.assign(ncols, 0);
+    b->h_off.resize(ncols);
+    b->h_bytes.resize(ncols);
+    b->h_val.resize(ncols);
+    b->have_col.assign(ncols, false);
+    b->have_val.assign(ncols, false);
+    b->h_fixed.resize(ncols);
+    b->fixed_stride.assign(ncols, 0);
+    uint64_t bytes_out = 0;
+    auto A = [&](size_t bytes, void **q) { return dev_alloc(d, bytes, q); };
+    void *q = nullptr;
+#define ALLOC_OR_FAIL(bytes, dst, T)     \
+    do {                                 \
+        rc = A((bytes), &q);             \
+        if (rc) {                        \
+            batch_release(b);            \
+            return rc;                   \
+        }                                \
+        dst = (T)q;                      \
+    } while (0)
+    if (!(p->flags & MDC_F_NO_RECOFF)) {
+        ALLOC_OR_FAIL((rows + 1) * 8, b->d_rec_off, uint64_t *);
+        bytes_out += (rows + 1) * 8;
+    }
+    for (uint32_t c = 0; c < ncols; ++c) {
+        b->nbytes[c] = p->h_totals[c];
+        ALLOC_OR_FAIL((rows + 1) * 4, b->d_off[c], uint32_t *);
+        ALLOC_OR_FAIL(b->nbytes[c] + 16, b->d_bytes[c], uint8_t *);
+        bytes_out += (rows + 1) * 4 + b->nbytes[c];
+        if (p->typed[c] != MDC_T_NONE) {
+            ALLOC_OR_FAIL(rows * 8 + 8, b->d_val[c], uint64_t *);
+            bytes_out += rows * 8;
+        }
+    }
+    ALLOC_OR_FAIL(rows * p->words * 4 + 4, b->d_valid, uint32_t *);
+    ALLOC_OR_FAIL(rows * p->words * 4 + 4, b->d_found, uint32_t *);
+    bytes_out += 2 * rows * p->words * 4;
+    ALLOC_OR_FAIL(3 * (size_t)ncols * sizeof(void *), b->d_ptrs, void *);
+    {
+        std::vector<void *> hp(3 * ncols);
+        for (uint32_t c = 0; c < ncols; ++c) {
+            hp[c] = b->d_off[c];
+            hp[ncols + c] = b->d_bytes[c];
+            hp[2 * ncols + c] = b->d_val[c];
+        }
+        HIP_TRY(hipMemcpyAsync(b->d_ptrs, hp.data(), hp.size() * sizeof(void *), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));  // hp is a stack object
+    }
+    if (ntiles == 0) {
+        // nothing to launch: every offset array is the single entry 0
+        for (uint32_t c = 0; c < ncols; ++c) HIP_TRY(hipMemsetAsync(b->d_off[c], 0, 4, s));
+        if (b->d_rec_off) HIP_TRY(hipMemsetAsync(b->d_rec_off, 0, 8, s));
+    }
+    P.rec_off = b->d_rec_off;
+    P.off = (uint32_t *const *)b->d_ptrs;
+    P.bytes = (uint8_t *const *)((void **)b->d_ptrs + ncols);
+    P.val = (uint64_t *const *)((void **)b->d_ptrs + 2 * ncols);
+    P.valid = b->d_valid;
+    P.found = b->d_found;
+    HIP_TRY(hipEventRecord(p->ev[2], s));
+    hipError_t le = launch_tile_kernel(true, P, s);
+    if (le != hipSuccess) {
+        batch_release(b);
+        return fail(MDC_ERR_HIP, "launch: %s", hipGetErrorString(le));
+    }
+    HIP_TRY(hipEventRecord(p->ev[3], s));
+    HIP_TRY(hipMemcpyAsync(p->h_totals + ncnt, p->d_status, 4, hipMemcpyDeviceToHost, s));
+    hipError_t se = hipStreamSynchronize(s);
+    if (se != hipSuccess) {
+        batch_release(b);
+        return fail(MDC_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(se));
+    }
+    rc = status_to_error((uint32_t)p->h_totals[ncnt]);
+    if (rc) {
+        batch_release(b);
+        return rc;
+    }
+    (void)hipEventElapsedTime(&t.write_ms, p->ev[2], p->ev[3]);
+    (void)hipEventElapsedTime(&t.total_ms, p->ev[0], p->ev[3]);
+    t.bytes_in = n;
+    t.bytes_out = bytes_out;
+    t.rows = (int64_t)rows;
+    t.tiles = (int)ntiles;
+    *out = b;
+    return MDC_OK;
+}
+
+extern "C" int mdc_parse_host(mdc_parser *p, const void *h_data, size_t n, mdc_batch **out) {
+    if (!p || !out) return fail(MDC_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    if (n && !h_data) return fail(MDC_ERR_ARG, "h_data is NULL");
+    Device *d = p->dev;
+    HIP_TRY(hipSetDevice(d->id));
+    void *dbuf = nullptr;
+    int rc = dev_alloc(d, n + 64, &dbuf);
+    if (rc) return rc;
+    if (n) {
+        hipError_t e = hipMemcpyAsync(dbuf, h_data, n, hipMemcpyHostToDevice, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        if (e != hipSuccess) {
+            dev_free(d, dbuf);
+            return fail(MDC_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+        }
+    }
+    rc = mdc_parse_device(p, dbuf, n, out);
+    dev_free(d, dbuf);
+    return rc;
+}
+
+extern "C" int mdc_parse_file(mdc_parser *p, const char *path, mdc_batch **out) {
+    if (!p || !out || !path) return fail(MDC_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(MDC_FILE_OPEN_FAILED, "open(%s) failed", path);
+    std::vector<uint8_t> buf;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        long sz = ftell(f);
+        if (sz > 0) buf.reserve((size_t)sz);
+        fseek(f, 0, SEEK_SET);
+    }
+    uint8_t tmp[1 << 16];
+    size_t got;
+    while ((got = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+    bool bad = ferror(f) != 0;
+    fclose(f);
+    if (bad) return fail(MDC_ERR_IO, "read(%s) failed", path);
+    return mdc_parse_host(p, buf.data(), buf.size(), out);
+}
+
+extern "C" int mdc_parser_last_timing(const mdc_parser *p, mdc_timing *t) {
+    if (!p || !t) return fail(MDC_ERR_ARG, "NULL argument");
+    *t = p->timing;
+    return MDC_OK;
+}
+
+extern "C" int mdc_parse_xml_buffer(const void *h_data, size_t n, const mdc_col *cols, int ncols,
+                                    const mdc_opts *opts, mdc_batch **out) {
+    mdc_parser *p = nullptr;
+    int rc = mdc_parser_create_xml(cols, ncols, opts, &p);
+    if (rc) return rc;
+    rc = mdc_parse_host(p, h_data, n, out);
+    mdc_parser_destroy(p);
+    return rc;
+}
+
+extern "C" int mdc_parse_xml_file(const char *path, const mdc_col *cols, int ncols, const mdc_opts *opts,
+                                  mdc_batch **out) {
+    mdc_parser *p = nullptr;
+    int rc = mdc_parser_create_xml(cols, ncols, opts, &p);
+    if (rc) return rc;
+    rc = mdc_parse_file(p, path, out);
+    mdc_parser_destroy(p);
+    return rc;
+}
+
+extern "C" int mdc_parse_csv_buffer(const void *h_data, size_t n, const char *sep, int bdelspace, int nfields,
+                                    const int *ilen, const mdc_opts *opts, mdc_batch **out) {
+    mdc_parser *p = nullptr;
+    int rc = mdc_parser_create_csv(sep, bdelspace, nfields, ilen, opts, &p);
+    if (rc) return rc;
+    rc = mdc_parse_host(p, h_data, n, out);
+    mdc_parser_destroy(p);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// batch accessors
+
+extern "C" int64_t mdc_batch_rows(const mdc_batch *b) { return b ? b->rows : -1; }
+extern "C" int mdc_batch_ncols(const mdc_batch *b) { return b ? b->ncols : -1; }
+extern "C" int mdc_batch_words_per_row(const mdc_batch *b) { return b ? (int)b->words : -1; }
+
+#define CHECK_COL(b, col)                                                   \
+    if (!(b)) return fail(MDC_ERR_ARG, "batch is NULL");                    \
+    if ((col) < 0 || (col) >= (b)->ncols) return fail(MDC_ERR_ARG, "column %d out of range", (col))
+
+extern "C" int mdc_batch_device_column(const mdc_batch *b, int col, const uint32_t **d_off,
+                                       const uint8_t **d_bytes, uint64_t *nbytes) {
+    CHECK_COL(b, col);
+    if (d_off) *d_off = b->d_off[col];
+    if (d_bytes) *d_bytes = b->d_bytes[col];
+    if (nbytes) *nbytes = b->nbytes[col];
+    return MDC_OK;
+}
+
+extern "C" int mdc_batch_device_values(const mdc_batch *b, int col, const uint64_t **d_val) {
+    CHECK_COL(b, col);
+    if (!b->d_val[col]) return fail(MDC_ERR_ARG, "column %d has no typed values", col);
+    if (d_val) *d_val = b->d_val[col];
+    return MDC_OK;
+}
+
+extern "C" int mdc_batch_device_masks(const mdc_batch *b, const uint32_t **d_valid, const uint32_t **d_found) {
+    if (!b) return fail(MDC_ERR_ARG, "batch is NULL");
+    if (d_valid) *d_valid = b->d_valid;
+    if (d_found) *d_found = b->d_found;
+    return MDC_OK;
+}
+
+extern "C" int mdc_batch_device_recoff(const mdc_batch *b, const uint64_t **d_rec_off) {
+    if (!b) return fail(MDC_ERR_ARG, "batch is NULL");
+    if (!b->d_rec_off) return fail(MDC_ERR_ARG, "record offsets were not requested");
+    if (d_rec_off) *d_rec_off = b->d_rec_off;
+    return MDC_OK;
+}
+
+static int d2h(Device *d, void *dst, const void *src, size_t n) {
+    if (!n) return MDC_OK;
+    HIP_TRY(hipSetDevice(d->id));
+    HIP_TRY(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+    return MDC_OK;
+}
+
+extern "C" int mdc_batch_host_column(mdc_batch *b, int col, const uint32_t **off, const uint8_t **bytes,
+                                     uint64_t *nbytes) {
+    CHECK_COL(b, col);
+    if (!b->have_col[col]) {
+        b->h_off[col].resize((size_t)b->rows + 1);
+        b->h_bytes[col].resize((size_t)b->nbytes[col] + 1);
+        int rc = d2h(b->dev, b->h_off[col].data(), b->d_off[col], ((size_t)b->rows + 1) * 4);
+        if (!rc) rc = d2h(b->dev, b->h_bytes[col].data(), b->d_bytes[col], (size_t)b->nbytes[col]);
+        if (rc) return rc;
+        b->have_col[col] = true;
+    }
+    if (off) *off = b->h_off[col].data();
+    if (bytes) *bytes = b->h_bytes[col].data();
+    if (nbytes) *nbytes = b->nbytes[col];
+    return MDC_OK;
+}
+
+extern "C" int mdc_batch_host_values(mdc_batch *b, int col, const uint64_t **val) {
+    CHECK_COL(b, col);
+    if (!b->d_val[col]) return fail(MDC_ERR_ARG, "column %d has no typed values", col);
+    if (!b->have_val[col]) {
+        b->h_val[col].resize((size_t)b->rows + 1);
+        int rc = d2h(b->dev, b->h_val[col].data(), b->d_val[col], (size_t)b->rows * 8);
+        if (rc) return rc;
+        b->have_val[col] = true;
+    }
+    if (val) *val = b->h_val[col].data();
+    return MDC_OK;
+}
+
+extern "C" int mdc_batch_host_masks(mdc_batch *b, const uint32_t **valid, const uint32_t **found) {
+    if (!b) return fail(MDC_ERR_ARG, "batch is NULL");
+    if (!b->have_masks) {
+        size_t cnt = (size_t)b->rows * b->words;
+        b->h_valid.resize(cnt + 1);
+        b->h_found.resize(cnt + 1);
+        int rc = d2h(b->dev, b->h_valid.data(), b->d_valid, cnt * 4);
+        if (!rc) rc = d2h(b->dev, b->h_found.data(), b->d_found, cnt * 4);
+        if (rc) return rc;
+        b->have_masks = true;
+    }
+    if (valid) *valid = b->h_valid.data();
+    if (found) *found = b->h_found.data();
+    return MDC_OK;
+}
+
+extern "C" int mdc_batch_host_recoff(mdc_batch *b, const uint64_t **rec_off) {
+    if (!b) return fail(MDC_ERR_ARG, "batch is NULL");
+    if (!b->d_rec_off) return fail(MDC_ERR_ARG, "record offsets were not requested");
+    if (!b->have_recoff) {
+        b->h_rec_off.resize((size_t)b->rows + 1);
+        int rc = d2h(b->dev, b->h_rec_off.data(), b->d_rec_off, ((size_t)b->rows + 1) * 8);
+        if (rc) return rc;
+        b->have_recoff = true;
+    }
+    if (rec_off) *rec_off = b->h_rec_off.data();
+    return MDC_OK;
+}
+
+extern "C" int mdc_batch_cell(mdc_batch *b, int64_t row, int col, const char **p, uint32_t *len) {
+    CHECK_COL(b, col);
+    if (row < 0 || row >= b->rows) return fail(MDC_ERR_ARG, "row out of range");
+    const uint32_t *off;
+    const uint8_t *bytes;
+    int rc = mdc_batch_host_column(b, col, &off, &bytes, nullptr);
+    if (rc) return rc;
+    if (p) *p = (const char *)bytes + off[row];
+    if (len) *len = off[row + 1] - off[row];
+    return MDC_OK;
+}
+
+extern "C" int mdc_batch_column_fixed(mdc_batch *b, int col, const char **base, size_t *stride) {
+    CHECK_COL(b, col);
+    if (b->h_fixed[col].empty()) {
+        const uint32_t *off;
+        int rc = mdc_batch_host_column(b, col, &off, nullptr, nullptr);
+        if (rc) return rc;
+        size_t st;
+        if (b->collen[col] > 0) {
+            st = (size_t)b->collen[col] + 1;
+        } else {
+            uint32_t mx = 0;
+            for (int64_t r = 0; r < b->rows; ++r) mx = off[r + 1] - off[r] > mx ? off[r + 1] - off[r] : mx;
+            st = (size_t)mx + 1;
+        }
+        if (st > 0xFFFFFFFFull) return fail(MDC_ERR_TOO_LARGE, "stride too large");
+        size_t total = (size_t)b->rows * st;
+        b->h_fixed[col].assign(total + 1, 0);
+        if (total) {
+            void *slab = nullptr;
+            rc = dev_alloc(b->dev, total, &slab);
+            if (rc) return rc;
+            hipError_t e = launch_fixed_stride(b->d_off[col], b->d_bytes[col], (uint8_t *)slab, (uint64_t)b->rows,
+                                               (uint32_t)st, b->dev->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(b->dev->stream);
+            if (e == hipSuccess) e = hipMemcpy(b->h_fixed[col].data(), slab, total, hipMemcpyDeviceToHost);
+            dev_free(b->dev, slab);
+            if (e != hipSuccess) return fail(MDC_ERR_HIP, "fixed-stride expansion: %s", hipGetErrorString(e));
+        }
+        b->fixed_stride[col] = st;
+    }
+    if (base) *base = b->h_fixed[col].data();
+    if (stride) *stride = b->fixed_stride[col];
+    return MDC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// library / device helpers
+
+extern "C" const char *mdc_version(void) { return "mdc_parse 0.1 (gfx950)"; }
+
+extern "C" int mdc_device_count(void) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) return fail(MDC_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return count;
+}
+
+extern "C" const char *mdc_strerror(int code) {
+    switch (code) {
+    case MDC_OK: return "ok";
+    case MDC_FILE_OPEN_FAILED: return "open file failed";
+    case MDC_ERR_ARG: return "bad argument";
+    case MDC_ERR_NO_DEVICE: return "no HIP device (no CPU fallback exists)";
+    case MDC_ERR_HIP: return "HIP runtime error";
+    case MDC_ERR_NOMEM: return "out of device memory";
+    case MDC_ERR_RECORD_TOO_LONG: return "record longer than the look-behind window";
+    case MDC_ERR_TOO_LARGE: return "column larger than 4 GiB";
+    case MDC_ERR_NUMERIC: return "numeric text beyond the exact-conversion range";
+    case MDC_ERR_IO: return "I/O error";
+    case MDC_ERR_INTERNAL: return "internal error";
+    default: return "unknown error";
+    }
+}
+
+extern "C" const char *mdc_last_error(void) { return g_err.c_str(); }
+
+extern "C" int mdc_device_alloc(int device, size_t n, void **d_ptr) {
+    if (!d_ptr) return fail(MDC_ERR_ARG, "d_ptr is NULL");
+    Device *d;
+    int rc = get_device(device, &d);
+    if (rc) return rc;
+    return dev_alloc(d, n + 64, d_ptr);
+}
+
+extern "C" int mdc_device_free(int device, void *d_ptr) {
+    Device *d;
+    int rc = get_device(device, &d);
+    if (rc) return rc;
+    dev_free(d, d_ptr);
+    return MDC_OK;
+}
+
+extern "C" int mdc_device_upload(int device, void *d_dst, const void *h_src, size_t n) {
+    Device *d;
+    int rc = get_device(device, &d);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(d->id));
+    if (n) HIP_TRY(hipMemcpy(d_dst, h_src, n, hipMemcpyHostToDevice));
+    return MDC_OK;
+}
+
+extern "C" int mdc_device_download(int device, void *h_dst, const void *d_src, size_t n) {
+    Device *d;
+    int rc = get_device(device, &d);
+    if (rc) return rc;
+    return d2h(d, h_dst, d_src, n);
+}
+
+extern "C" int mdc_device_synchronize(int device) {
+    Device *d;
+    int rc = get_device(device, &d);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(d->id));
+    HIP_TRY(hipDeviceSynchronize());
+    return MDC_OK;
+}

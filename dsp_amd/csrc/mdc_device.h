@@ -1,0 +1,120 @@
+// mdc_device.h -- structures shared by the host side (mdc_abi.cpp) and the gfx950 kernels
+// (mdc_kernels.hip).  Everything here is plain data laid out identically on both sides.
+#pragma once
+#include <stdint.h>
+
+namespace mdc {
+
+// ---- tile geometry ---------------------------------------------------------------------
+// A tile is TILE consecutive input bytes.  A tile owns every record whose terminating '\n'
+// lies inside it; the first owned record may start up to LBMAX bytes in front of the tile
+// (look-behind).  The block keeps [tile_start-LBMAX, tile_start+TILE) in LDS, byte `pos` at
+// LDS index pos - tile_start + LBMAX.
+constexpr int BLOCK = 256;
+constexpr int TILE = 16384;
+constexpr int LBMAX = 8192;
+constexpr int CHUNK = 16;                                // bytes per lane per step (one dwordx4)
+constexpr int NCH = (TILE + LBMAX) / CHUNK;              // chunks in the LDS image
+constexpr int CPT = NCH / BLOCK;                         // chunks per thread in the rank scan
+constexpr int DATA_SLACK = 64;                           // readable bytes past the image
+constexpr int LB_FIRST = 512;                            // first look-behind window
+constexpr int LB_STEP = BLOCK * CHUNK;                   // later windows
+constexpr int MAX_COLS = 128;
+constexpr int MAX_ENDBZ = 32;
+constexpr int MAX_SEP = 16;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+static_assert(NCH % BLOCK == 0, "chunk count must divide evenly over the block");
+
+// filter level of a cell: nested projections char (everything) > number > date
+enum : uint8_t { LVL_CHAR = 0, LVL_NUMBER = 1, LVL_DATE = 2 };
+
+enum : uint32_t { MODE_XML = 0, MODE_CSV = 1 };
+
+// status bits raised by the kernels (OR-ed into one device word)
+enum : uint32_t {
+    ST_RECORD_TOO_LONG = 1u,
+    ST_NUMERIC_RANGE = 2u,
+    ST_INTERNAL = 4u,
+};
+
+struct DevCol {
+    uint8_t name[32];
+    uint8_t namelen;
+    uint8_t level;   // LVL_*
+    uint8_t typed;   // MDC_T_*
+    uint8_t pad;
+    int32_t collen;  // clip length, <=0: none
+};
+static_assert(sizeof(DevCol) == 40, "DevCol layout");
+
+#ifdef __HIPCC__
+#define MDC_HD __host__ __device__
+#else
+#define MDC_HD
+#endif
+
+// hash of a tag key (the first eight bytes of text+'>' as two little-endian words)
+MDC_HD inline uint32_t ht_hash(uint32_t lo, uint32_t hi) {
+    uint32_t h = lo * 0x9E3779B1u + hi * 0x85EBCA77u;
+    return h ^ (h >> 15);
+}
+
+// open-addressed table of tag texts.  key = first min(8, tlen+1) bytes of text+'>'.
+struct HtEntry {
+    uint32_t klo, khi;
+    uint32_t meta;  // bit31 used | col<<16 | kind<<8 | tlen
+    uint32_t pad;
+};
+
+struct SchemaHdr {
+    uint32_t ncols, npat, ht_mask, endbz_len;
+    uint32_t carry, mode, words, sep_len;
+    uint32_t bdelspace, any_typed, r1, r2;
+    uint8_t endbz[MAX_ENDBZ];
+    uint8_t sep[MAX_SEP];
+    // followed by DevCol[ncols], then HtEntry[ht_mask+1] (16-byte aligned)
+};
+static_assert(sizeof(SchemaHdr) % 16 == 0, "SchemaHdr must keep 16-byte alignment");
+
+// byte offsets of the LDS regions (computed on the host from the schema)
+struct LdsLayout {
+    uint32_t data;    // TILE+LBMAX+DATA_SLACK bytes
+    uint32_t evt;     // RB*npat u32 (first positions); reused as per-cell lengths/offsets
+    uint32_t dstart;  // RB*ncols u32
+    uint32_t dlen;    // RB*ncols u32 (level in bits 30..31)
+    uint32_t cterm;   // NCH u16: terminator bit mask per chunk
+    uint32_t cpre;    // NCH u16: terminators in front of the chunk
+    uint32_t recend;  // (RB+1) u32
+    uint32_t vmask;   // RB*words u32
+    uint32_t fmask;   // RB*words u32
+    uint32_t coltot;  // 3*(ncols+1) u32: batch totals, tile totals, stage bases
+    uint32_t stage;   // stage_cap bytes
+    uint32_t schema;  // schema blob
+    uint32_t misc;    // 64 u32 of block-wide scalars
+    uint32_t total;
+    uint32_t RB;         // records per batch
+    uint32_t stage_cap;
+};
+
+struct TileParams {
+    const uint8_t *data;
+    uint64_t n;
+    const uint8_t *schema;
+    uint32_t schema_bytes;
+    uint32_t ntiles;
+    LdsLayout L;
+    // count mode output / write mode input
+    uint32_t *tile_counts;       // [ntiles][ncols+1]: bytes per column, then rows
+    const uint64_t *tile_base;   // [ntiles+1][ncols+1] exclusive prefix (row ntiles = totals)
+    // write mode outputs
+    uint64_t *rec_off;           // rows+1 or null
+    uint32_t *const *off;        // [ncols] -> rows+1
+    uint8_t *const *bytes;       // [ncols]
+    uint64_t *const *val;        // [ncols] (null when untyped)
+    uint32_t *valid;             // rows*words
+    uint32_t *found;             // rows*words
+    uint32_t *status;
+};
+
+}  // namespace mdc

@@ -1,0 +1,190 @@
+/*
+ * mdc_parse.h -- C ABI of the MI355X bulk record parser (libmdc_parse.so).
+ *
+ * Drop-in boundary for the one data-parallel path of the MDC toolkit: the xmltodb ingest
+ * loop (reference tools/xmltodb.cpp:263-304) and the delimited twin built on ccmdstr.  The
+ * reference has no FFI; the per-record C++ calls this library replaces, in bulk, are cited
+ * on every entry point (paths relative to the reference root).  Plain pointers and sizes
+ * only; no C++ or torch types cross this boundary.
+ *
+ * Model: a *parser* binds a schema to one GPU and owns reusable device workspace; parsing a
+ * buffer (already in HBM, or on the host, or a file) yields a *batch*: for every column a
+ * compact byte arena + u32 offsets (cell r = bytes[off[r]..off[r+1])), optional typed
+ * values, and per-row valid/found bit masks.  Batches live in device memory; host mirrors
+ * are made on request.  Every function returns MDC_OK (0) or a negative MDC_ERR_* code,
+ * except where a reference file-level code is mirrored (MDC_FILE_OPEN_FAILED == 5,
+ * tools/xmltodb.cpp:256-261).  Nothing throws and no output is touched on failure.
+ *
+ * Thread safety: a parser (and the batches it produced) may be used by one thread at a
+ * time; different parsers are independent.  The HIP runtime is initialised lazily by the
+ * first call that needs the device, never at load time (xmltodb closes fds 0-63 in
+ * main() before any work: tools/xmltodb.cpp:80).
+ */
+#ifndef MDC_PARSE_H
+#define MDC_PARSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- schema ------------------------------------------------------------------------- */
+
+/* One table column; same layout and meaning as ctcols::st_col (tools/_tools.h:21-27) after
+ * the type normalisation of ctcols::allcols (tools/_tools.cpp:47-71): datatype is "char",
+ * "date" (collen 14) or "number" (collen 22); collen<=0 means "no clip". */
+typedef struct mdc_col {
+    char colname[32];
+    char datatype[32];
+    int collen;
+    int pkseq;
+} mdc_col;
+
+/* Typed conversion applied to a cell's text; each is the reference overload named
+ * (public/_public.cpp:506-625 for getxmlbuffer, :339-446 for ccmdstr::getvalue). */
+enum {
+    MDC_T_NONE = 0,
+    MDC_T_I32 = 1,  /* stoi(picknumber(s,true))       -> int64 slot (sign-extended)      */
+    MDC_T_U32 = 2,  /* stoi(picknumber(s))            -> uint64 slot                     */
+    MDC_T_I64 = 3,  /* stol(picknumber(s,true))                                          */
+    MDC_T_U64 = 4,  /* stoul(picknumber(s))                                              */
+    MDC_T_F64 = 5,  /* stod(picknumber(s,true,true))  -> IEEE-754 binary64 bits          */
+    MDC_T_F32 = 6,  /* stof(picknumber(s,true,true))  -> binary32 bits in the low word   */
+    MDC_T_BOOL = 7, /* toupper(s)=="TRUE"             -> 0/1                             */
+    MDC_T_DEFAULT = -1 /* number -> F64, date -> I64, char -> NONE                       */
+};
+
+/* ---- status codes ------------------------------------------------------------------- */
+enum {
+    MDC_OK = 0,
+    MDC_FILE_OPEN_FAILED = 5,   /* same value as _xmltodb()'s "open failed" (xmltodb.cpp:260) */
+    MDC_ERR_ARG = -1,           /* bad argument / unsupported schema (see mdc_last_error)     */
+    MDC_ERR_NO_DEVICE = -2,     /* no usable HIP device: there is no CPU fallback             */
+    MDC_ERR_HIP = -3,           /* a HIP runtime call failed                                  */
+    MDC_ERR_NOMEM = -4,
+    MDC_ERR_RECORD_TOO_LONG = -5, /* a record longer than the parser's look-behind window   */
+    MDC_ERR_TOO_LARGE = -6,     /* a column's cells exceed 4 GiB in one batch: split input    */
+    MDC_ERR_NUMERIC = -7,       /* numeric text beyond the exact-conversion range            */
+    MDC_ERR_IO = -8,
+    MDC_ERR_INTERNAL = -9
+};
+
+/* ---- options ------------------------------------------------------------------------ */
+typedef struct mdc_opts {
+    int device;          /* HIP device ordinal; -1 = device 0                               */
+    const char *endbz;   /* record end mark before '\n' (cifile::readline's endbz,          */
+                         /* public/_public.cpp:866); NULL = "<endl/>", "" = plain lines    */
+    int carry;           /* 1 = splitbuffer semantics: a missing tag keeps the previous      */
+                         /* column's value (xmltodb.cpp:494-518); 0 = independent            */
+                         /* getxmlbuffer per column (missing tag: empty cell, found bit 0)  */
+    const int *typed;    /* per column MDC_T_*; NULL = MDC_T_DEFAULT for every column       */
+    unsigned flags;      /* MDC_F_*                                                          */
+} mdc_opts;
+
+enum {
+    MDC_F_NO_RECOFF = 1u  /* do not materialise the record-offset array                     */
+};
+
+typedef struct mdc_parser mdc_parser;
+typedef struct mdc_batch mdc_batch;
+
+/* Per-parse device timings in milliseconds (HIP events on the parser's stream). */
+typedef struct mdc_timing {
+    float count_ms;  /* sizing pass (tile kernel, count mode)        */
+    float scan_ms;   /* tile-offset scan                              */
+    float write_ms;  /* tile kernel, write mode: the dominant kernel  */
+    float total_ms;  /* first launch to last completion               */
+    uint64_t bytes_in;
+    uint64_t bytes_out; /* algorithmic output bytes actually written  */
+    int64_t rows;
+    int tiles;
+} mdc_timing;
+
+/* ---- library ------------------------------------------------------------------------ */
+
+const char *mdc_version(void);
+/* number of usable HIP devices, or a negative MDC_ERR_* */
+int mdc_device_count(void);
+const char *mdc_strerror(int code);
+/* text of the last error on the calling thread ("" if none) */
+const char *mdc_last_error(void);
+
+/* ---- parsers ------------------------------------------------------------------------ */
+
+/* Replaces, per record: cifile::readline(buf,endbz) (public/_public.cpp:866-892) +
+ * splitbuffer (tools/xmltodb.cpp:492-522), i.e. getxmlbuffer(xml,colname,temp,collen)
+ * (public/_public.cpp:461-481) + picknumber(temp,temp,..) (public/_public.cpp:178-204) +
+ * vcolvalue[i]=temp.c_str() for every column of the schema.  Column names must not contain
+ * '>' or '\n' and the schema may hold at most 128 columns (MDC_ERR_ARG otherwise). */
+int mdc_parser_create_xml(const mdc_col *cols, int ncols, const mdc_opts *opts, mdc_parser **out);
+
+/* Replaces, per line: cifile::readline(buf) + ccmdstr::splittocmd(buf,sep,bdelspace)
+ * (public/_public.cpp:274-302) + getvalue(f,string&,ilen[f]) (:304-317) and the typed
+ * getvalue overloads (:339-446) for fields 0..nfields-1.  sep must be 1..16 bytes without
+ * '\n'.  opts->typed/ilen may be NULL. */
+int mdc_parser_create_csv(const char *sep, int bdelspace, int nfields, const int *ilen,
+                          const mdc_opts *opts, mdc_parser **out);
+
+void mdc_parser_destroy(mdc_parser *p);
+
+/* Parse n bytes that are already resident in device memory of the parser's GPU.  d_data
+ * must be 16-byte aligned and stay valid until the call returns (the call synchronises the
+ * parser's stream before returning). */
+int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc_batch **out);
+/* Parse n bytes of host memory (copied to the device through a pinned staging buffer). */
+int mdc_parse_host(mdc_parser *p, const void *h_data, size_t n, mdc_batch **out);
+/* Parse a whole file; MDC_FILE_OPEN_FAILED (5) when it cannot be opened. */
+int mdc_parse_file(mdc_parser *p, const char *path, mdc_batch **out);
+/* timings of the most recent successful parse on this parser */
+int mdc_parser_last_timing(const mdc_parser *p, mdc_timing *t);
+
+/* One-shot forms (create a parser, parse, destroy it). */
+int mdc_parse_xml_buffer(const void *h_data, size_t n, const mdc_col *cols, int ncols,
+                         const mdc_opts *opts, mdc_batch **out);
+int mdc_parse_xml_file(const char *path, const mdc_col *cols, int ncols, const mdc_opts *opts,
+                       mdc_batch **out);
+int mdc_parse_csv_buffer(const void *h_data, size_t n, const char *sep, int bdelspace,
+                         int nfields, const int *ilen, const mdc_opts *opts, mdc_batch **out);
+
+/* ---- batches ------------------------------------------------------------------------ */
+
+int64_t mdc_batch_rows(const mdc_batch *b);          /* totalcount of xmltodb.cpp:266 */
+int mdc_batch_ncols(const mdc_batch *b);
+int mdc_batch_words_per_row(const mdc_batch *b);     /* u32 mask words per row */
+
+/* Device views (valid until mdc_batch_free). */
+int mdc_batch_device_column(const mdc_batch *b, int col, const uint32_t **d_off,
+                            const uint8_t **d_bytes, uint64_t *nbytes);
+int mdc_batch_device_values(const mdc_batch *b, int col, const uint64_t **d_val);
+int mdc_batch_device_masks(const mdc_batch *b, const uint32_t **d_valid, const uint32_t **d_found);
+int mdc_batch_device_recoff(const mdc_batch *b, const uint64_t **d_rec_off);
+
+/* Host mirrors (copied from the device on first use; owned by the batch). */
+int mdc_batch_host_column(mdc_batch *b, int col, const uint32_t **off, const uint8_t **bytes,
+                          uint64_t *nbytes);
+int mdc_batch_host_values(mdc_batch *b, int col, const uint64_t **val);
+int mdc_batch_host_masks(mdc_batch *b, const uint32_t **valid, const uint32_t **found);
+int mdc_batch_host_recoff(mdc_batch *b, const uint64_t **rec_off);
+/* cell (row,col) on the host: what vcolvalue[col] holds after splitbuffer for record row */
+int mdc_batch_cell(mdc_batch *b, int64_t row, int col, const char **p, uint32_t *len);
+/* Column as fixed-stride NUL-terminated slots, stride = max(cell length in the batch)+1 or
+ * collen+1 when the schema has collen>0: the layout sqlstatement::bindin(pos,string&,len)
+ * binds (public/db/oracle/_ooci.cpp:568-573), ready for an array bind.  Host memory owned
+ * by the batch. */
+int mdc_batch_column_fixed(mdc_batch *b, int col, const char **base, size_t *stride);
+
+void mdc_batch_free(mdc_batch *b);
+
+/* ---- device memory helpers (so callers without a HIP binding can stage inputs) ------ */
+int mdc_device_alloc(int device, size_t n, void **d_ptr);
+int mdc_device_free(int device, void *d_ptr);
+int mdc_device_upload(int device, void *d_dst, const void *h_src, size_t n);
+int mdc_device_download(int device, void *h_dst, const void *d_src, size_t n);
+int mdc_device_synchronize(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

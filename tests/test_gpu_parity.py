@@ -1,0 +1,216 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU checker and the golden
+vectors.  Bit-exact for every output (cell bytes, offsets, record offsets, masks, typed values)."""
+import numpy as np
+import pytest
+
+import cases
+import golden_io
+from dsp_amd import capi, gen, schema
+from dsp_amd.schema import Col
+from util import assert_batches_equal
+
+pytestmark = pytest.mark.gpu
+
+ALL_T = list(range(1, 8))
+
+
+def gpu_xml(data, cols, typed=None, endbz="<endl/>", carry=True):
+    p = capi.Parser.xml(cols, typed=typed, endbz=endbz, carry=carry)
+    try:
+        b = p.parse_host(data)
+        return b.to_host()
+    finally:
+        p.close()
+
+
+def gpu_csv(data, sep, nfields, ilen=None, typed=None, bdelspace=False):
+    p = capi.Parser.csv(sep, nfields, ilen=ilen, typed=typed, bdelspace=bdelspace)
+    try:
+        return p.parse_host(data).to_host()
+    finally:
+        p.close()
+
+
+def test_library_loads_on_gpu():
+    assert capi.lib().mdc_device_count() >= 1
+
+
+@pytest.mark.parametrize("case", golden_io.xml_cases(), ids=lambda c: c["name"])
+def test_golden_xml(case):
+    print("case", case["name"], flush=True)
+    got = gpu_xml(case["data"], case["cols"], typed=case["typed"], endbz=case["endbz"], carry=case["carry"])
+    assert_batches_equal(got, case["expect"], case["name"])
+
+
+@pytest.mark.parametrize("case", golden_io.csv_cases(), ids=lambda c: c["name"])
+def test_golden_csv(case):
+    print("case", case["name"], flush=True)
+    got = gpu_csv(case["data"], case["sep"], case["nfields"], ilen=case["ilen"], typed=case["typed"],
+                  bdelspace=case["bdelspace"])
+    assert_batches_equal(got, case["expect"], case["name"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("schema_name", ["SMALL", "LONGNAMES", "ODD"])
+def test_mutated_xml(port, seed, schema_name):
+    cols = getattr(cases, schema_name)
+    data = cases.mutated_xml(100 + seed, 700, cols, damage=0.15 + 0.07 * seed)
+    typed = [ALL_T[(seed + i) % len(ALL_T)] for i in range(len(cols))]
+    for carry in (True, False):
+        print("mutated", schema_name, seed, carry, len(data), flush=True)
+        got = gpu_xml(data, cols, typed=typed, carry=carry)
+        exp = port.parse_xml(data, cols, typed=typed, carry=carry)
+        assert_batches_equal(got, exp, f"mutated {schema_name} {seed} carry={carry}")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_soup_xml(port, seed):
+    for cols in (cases.SMALL, cases.ODD):
+        data = cases.soup_xml(200 + seed, 30000, cols)
+        print("soup", seed, len(data), flush=True)
+        got = gpu_xml(data, cols)
+        exp = port.parse_xml(data, cols)
+        assert_batches_equal(got, exp, f"soup {seed}")
+
+
+@pytest.mark.parametrize("rows", [1, 95, 96, 1000, 20000])
+def test_mind_files(port, rows):
+    data, n = gen.mind_xml(rows=rows)
+    print("mind", rows, len(data), flush=True)
+    got = gpu_xml(data, schema.ZHOBTMIND)
+    exp = port.parse_xml(data, schema.ZHOBTMIND)
+    assert got.rows == n
+    assert_batches_equal(got, exp, f"mind rows={rows}")
+
+
+def test_code_file(port):
+    data, n = gen.code_xml()
+    got = gpu_xml(data, schema.ZHOBTCODE)
+    exp = port.parse_xml(data, schema.ZHOBTCODE)
+    assert got.rows == n == 839
+    assert_batches_equal(got, exp, "code")
+
+
+def test_short_records_many_batches(port):
+    # 8-byte records: 2048 records per tile, many batches per tile
+    data = b"<endl/>\n" * 5000 + b"<a>1</a><endl/>\n" * 3000
+    got = gpu_xml(data, cases.SMALL)
+    exp = port.parse_xml(data, cases.SMALL)
+    assert_batches_equal(got, exp, "short records")
+
+
+@pytest.mark.parametrize("reclen", [100, 1000, 5000, 8000])
+def test_records_straddling_tiles(port, reclen):
+    # records whose start lies far in front of the tile that holds their terminator
+    rng = np.random.default_rng(reclen)
+    recs = []
+    for i in range(40):
+        pad = bytes(rng.integers(97, 123, size=reclen - 40, dtype=np.uint8))
+        recs.append(b"<a>%d</a><ab>" % i + pad + b"</ab><b>%d.5</b><endl/>\n" % i)
+    data = b"".join(recs)
+    got = gpu_xml(data, cases.SMALL)
+    exp = port.parse_xml(data, cases.SMALL)
+    assert_batches_equal(got, exp, f"straddle {reclen}")
+
+
+def test_record_too_long_is_an_error():
+    data = b"<a>1</a>" + b"x" * 40000 + b"<endl/>\n"
+    with pytest.raises(capi.MdcError) as e:
+        gpu_xml(data, cases.SMALL)
+    assert e.value.code == capi.MDC_ERR_RECORD_TOO_LONG
+
+
+def test_long_cells_bypass_staging(port):
+    # cells larger than the LDS staging area take the direct store path
+    recs = [b"<ab>" + bytes([65 + (i % 26)]) * 3000 + b"</ab><a>k%d</a><endl/>\n" % i for i in range(30)]
+    data = b"".join(recs)
+    got = gpu_xml(data, cases.SMALL)
+    exp = port.parse_xml(data, cases.SMALL)
+    assert_batches_equal(got, exp, "long cells")
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("sep", [",", "~!~", " "])
+def test_fuzz_csv(port, seed, sep):
+    data = cases.fuzz_csv(300 + seed, 3000, sep, 6)
+    typed = [ALL_T[(seed + i) % len(ALL_T)] for i in range(6)]
+    for bdel in (False, True):
+        got = gpu_csv(data, sep, 6, ilen=[0, 0, 3, 0, 0, 1], typed=typed, bdelspace=bdel)
+        exp = port.parse_csv(data, sep, 6, ilen=[0, 0, 3, 0, 0, 1], typed=typed, bdelspace=bdel)
+        assert_batches_equal(got, exp, f"csv {seed} {sep!r} {bdel}")
+
+
+def test_mind_csv(port):
+    data, n = gen.mind_csv(rows=30000)
+    got = gpu_csv(data, ",", 10, typed=schema.MIND_CSV_TYPED)
+    exp = port.parse_csv(data, ",", 10, typed=schema.MIND_CSV_TYPED)
+    assert got.rows == n
+    assert_batches_equal(got, exp, "mind csv")
+
+
+def test_numeric_conversion_exact(port):
+    # decimal -> binary64/binary32 must be correctly rounded for every digit count up to 38
+    rng = np.random.default_rng(20240519)
+    vals = []
+    for nd in range(1, 39):
+        for _ in range(60):
+            digits = "".join(str(d) for d in rng.integers(0, 10, size=nd))
+            k = int(rng.integers(0, nd + 1))
+            s = digits[: nd - k] + "." + digits[nd - k:] if k else digits
+            if rng.random() < 0.3:
+                s = "-" + s
+            vals.append(s)
+    vals += ["9007199254740993", "9007199254740992.5", "0.1", "0.3", "4.35", "2.5", "16777217", "16777216.5",
+             "0.000000000000000000000000000000000000011", "340282350000000000000000000000000000000"[:38]]
+    cols = [Col("d", "char", 0), Col("f", "char", 0), Col("i", "char", 0)]
+    data = b"".join(b"<d>%s</d><f>%s</f><i>%s</i><endl/>\n" % (v.encode(), v.encode(), v.encode()) for v in vals)
+    typed = [capi_t("F64"), capi_t("F32"), capi_t("I64")]
+    got = gpu_xml(data, cols, typed=typed, carry=False)
+    exp = port.parse_xml(data, cols, typed=typed, carry=False)
+    assert_batches_equal(got, exp, "numeric")
+
+
+def capi_t(name):
+    return {"I32": 1, "U32": 2, "I64": 3, "U64": 4, "F64": 5, "F32": 6, "BOOL": 7}[name]
+
+
+def test_numeric_beyond_exact_range_is_an_error():
+    data = b"<d>0.%s1</d><endl/>\n" % (b"0" * 60)
+    with pytest.raises(capi.MdcError) as e:
+        gpu_xml(data, [Col("d", "char", 0)], typed=[5], carry=False)
+    assert e.value.code == capi.MDC_ERR_NUMERIC
+
+
+def test_parse_file_and_accessors(tmp_path, port):
+    data, n = gen.mind_xml(rows=300)
+    f = tmp_path / "ZHOBTMIND_20240519162835_togxpt_1.xml"
+    f.write_bytes(bytes(data))
+    p = capi.Parser.xml(schema.ZHOBTMIND)
+    b = p.parse_file(str(f))
+    exp = port.parse_xml(data, schema.ZHOBTMIND)
+    assert b.rows == n
+    for r in (0, 1, 150, 299):
+        for c in range(11):
+            assert b.cell(r, c) == exp.cell(r, c)
+    slab, stride = b.column_fixed(1)   # ddatetime: collen 14 -> stride 15
+    assert stride == 15
+    for r in (0, 7, 299):
+        assert bytes(slab[r]).rstrip(b"\0") == exp.cell(r, 1)
+    with pytest.raises(capi.MdcError) as e:
+        p.parse_file(str(tmp_path / "missing.xml"))
+    assert e.value.code == capi.MDC_FILE_OPEN_FAILED
+    p.close()
+
+
+def test_device_resident_input(port):
+    data, n = gen.mind_xml(nbytes=4 << 20)
+    p = capi.Parser.xml(schema.ZHOBTMIND)
+    d = capi.DeviceBuffer(data)
+    b = p.parse_device(d.ptr, d.n)
+    got = b.to_host()
+    exp = port.parse_xml(data, schema.ZHOBTMIND)
+    assert_batches_equal(got, exp, "device resident")
+    t = p.timing()
+    assert t.rows == n and t.bytes_in == len(data) and t.write_ms > 0
+    d.free()
+    p.close()
