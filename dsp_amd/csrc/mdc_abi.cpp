@@ -23,6 +23,9 @@ namespace mdc {
 hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t stream);
 hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt,
                              hipStream_t stream);
+hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_t *const *bytes,
+                             uint64_t *const *val, uint32_t *valid, const uint32_t *found, uint64_t rows,
+                             uint32_t ncols, hipStream_t stream);
 hipError_t launch_fixed_stride(const uint32_t *off, const uint8_t *bytes, uint8_t *slab, uint64_t rows,
                                uint32_t stride, hipStream_t stream);
 }  // namespace mdc
@@ -431,9 +434,6 @@ static int ensure_workspace(mdc_parser *p, size_t ntiles) {
 static int status_to_error(uint32_t st) {
     if (st & ST_RECORD_TOO_LONG)
         return fail(MDC_ERR_RECORD_TOO_LONG, "a record is longer than the %d-byte look-behind window", LBMAX);
-    if (st & ST_NUMERIC_RANGE)
-        return fail(MDC_ERR_NUMERIC,
-                    "a floating-point field has more than 38 significant or fractional digits");
     if (st) return fail(MDC_ERR_INTERNAL, "kernel status %#x", st);
     return MDC_OK;
 }
@@ -472,7 +472,7 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     HIP_TRY(hipMemcpyAsync(p->h_totals, p->d_base + ntiles * ncnt, ncnt * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(p->h_totals + ncnt, p->d_status, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    rc = status_to_error((uint32_t)p->h_totals[ncnt]);
+    rc = status_to_error((uint32_t)p->h_totals[ncnt] & ~ST_NUMERIC_RANGE);
     if (rc) return rc;
     mdc_timing &t = p->timing;
     (void)hipEventElapsedTime(&t.count_ms, p->ev[0], p->ev[1]);
@@ -565,7 +565,19 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
         batch_release(b);
         return fail(MDC_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(se));
     }
-    rc = status_to_error((uint32_t)p->h_totals[ncnt]);
+    uint32_t st = (uint32_t)p->h_totals[ncnt];
+    if (st & ST_NUMERIC_RANGE) {
+        // some floating-point texts need the multi-precision stage
+        le = launch_long_float((const uint8_t *)p->d_blob, P.off, P.bytes, P.val, b->d_valid, b->d_found, rows, ncols,
+                               s);
+        if (le == hipSuccess) le = hipStreamSynchronize(s);
+        if (le != hipSuccess) {
+            batch_release(b);
+            return fail(MDC_ERR_HIP, "long_float: %s", hipGetErrorString(le));
+        }
+        st &= ~ST_NUMERIC_RANGE;
+    }
+    rc = status_to_error(st);
     if (rc) {
         batch_release(b);
         return rc;

@@ -26,6 +26,7 @@
 
 #include "mdc_device.h"
 #include "mdc_numparse.h"
+#include "mdc_bignum.h"
 
 namespace mdc {
 
@@ -651,8 +652,51 @@ __global__ __launch_bounds__(256) void fixed_stride_kernel(const uint32_t *off, 
     }
 }
 
+// Second stage of the typed conversion: cells whose text is beyond the 128-bit exact range
+// (flagged ST_NUMERIC_RANGE by the tile kernel, which left them invalid) are converted with
+// multi-precision arithmetic, reading the cell text back from the column arena.
+__global__ __launch_bounds__(256) void long_float_kernel(const uint8_t *schema, uint32_t *const *off,
+                                                         uint8_t *const *bytes, uint64_t *const *val,
+                                                         uint32_t *valid, const uint32_t *found, uint64_t rows) {
+    const SchemaHdr *H = (const SchemaHdr *)schema;
+    const DevCol *cols = (const DevCol *)(H + 1);
+    const uint32_t ncols = H->ncols, W = H->words;
+    const bool always = H->carry != 0 && H->mode == MODE_XML;
+    const uint64_t total = rows * ncols;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / ncols;
+        const uint32_t c = (uint32_t)(i - r * ncols);
+        const uint32_t typed = cols[c].typed;
+        if (typed != T_F64 && typed != T_F32) continue;
+        if (!always && !((found[r * W + (c >> 5)] >> (c & 31)) & 1u)) continue;
+        const uint32_t o = off[c][r], len = off[c][r + 1] - o;
+        if (len <= 38) continue;
+        uint64_t v = 0;
+        bool ok = false, range = false;
+        cell_walk<false>(bytes[c] + o, len, LVL_CHAR, false, typed, nullptr, v, ok, range);
+        if (!range) continue;
+        if (big_convert(bytes[c] + o, len, typed == T_F64, v)) {
+            val[c][r] = v;
+            atomicOr(&valid[r * W + (c >> 5)], 1u << (c & 31));
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers (called from mdc_abi.cpp)
+
+hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_t *const *bytes,
+                             uint64_t *const *val, uint32_t *valid, const uint32_t *found, uint64_t rows,
+                             uint32_t ncols, hipStream_t stream) {
+    if (rows == 0) return hipSuccess;
+    uint64_t total = rows * ncols;
+    uint32_t blocks = (uint32_t)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(long_float_kernel, dim3(blocks), dim3(256), 0, stream, schema, off, bytes, val, valid, found,
+                       rows);
+    return hipGetLastError();
+}
 
 hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t stream) {
     if (P.ntiles == 0) return hipSuccess;

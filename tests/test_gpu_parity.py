@@ -135,6 +135,7 @@ def test_fuzz_csv(port, seed, sep):
     data = cases.fuzz_csv(300 + seed, 3000, sep, 6)
     typed = [ALL_T[(seed + i) % len(ALL_T)] for i in range(6)]
     for bdel in (False, True):
+        print("csv", seed, repr(sep), bdel, flush=True)
         got = gpu_csv(data, sep, 6, ilen=[0, 0, 3, 0, 0, 1], typed=typed, bdelspace=bdel)
         exp = port.parse_csv(data, sep, 6, ilen=[0, 0, 3, 0, 0, 1], typed=typed, bdelspace=bdel)
         assert_batches_equal(got, exp, f"csv {seed} {sep!r} {bdel}")
@@ -174,11 +175,34 @@ def capi_t(name):
     return {"I32": 1, "U32": 2, "I64": 3, "U64": 4, "F64": 5, "F32": 6, "BOOL": 7}[name]
 
 
-def test_numeric_beyond_exact_range_is_an_error():
-    data = b"<d>0.%s1</d><endl/>\n" % (b"0" * 60)
-    with pytest.raises(capi.MdcError) as e:
-        gpu_xml(data, [Col("d", "char", 0)], typed=[5], carry=False)
-    assert e.value.code == capi.MDC_ERR_NUMERIC
+def test_long_numeric_texts(port):
+    # more than 38 digits: the multi-precision stage; includes halfway cases, subnormals that
+    # are exact, overflow/underflow (ERANGE -> invalid) and very long tails
+    rng = np.random.default_rng(7)
+    vals = ["0." + "0" * 60 + "1", "1" + "0" * 40, "9007199254740993" + "0" * 30 + "." + "0" * 50 + "1",
+            "9007199254740992.5" + "0" * 60, "9007199254740992.5" + "0" * 60 + "1",
+            "1" + "0" * 308, "1" + "0" * 309, "17976931348623157" + "0" * 292, "17976931348623159" + "0" * 292,
+            "0." + "0" * 307 + "22250738585072014", "0." + "0" * 323 + "49406564584124654",
+            "0." + "0" * 400 + "1", "0." + "0" * 37 + "11754943508222875", "0." + "0" * 44 + "14",
+            "34028234663852886" + "0" * 22, "34028235677973366" + "0" * 22, "3" * 900, "0." + "3" * 2000,
+            "123456789" * 100 + "." + "987654321" * 100]
+    # 2^-1074 and 2^-149 written out exactly
+    from fractions import Fraction
+    for e in (1074, 149, 1070, 140):
+        fr = Fraction(1, 2 ** e)
+        digs = str(fr.numerator * 10 ** e // fr.denominator).rjust(e, "0")
+        vals.append("0." + digs)
+        vals.append("0." + digs + "1")
+    for _ in range(150):
+        nd = int(rng.integers(39, 400))
+        digits = "".join(str(d) for d in rng.integers(0, 10, size=nd))
+        k = int(rng.integers(0, nd + 1))
+        vals.append((digits[: nd - k] + "." + digits[nd - k:]) if k else digits)
+    cols = [Col("d", "char", 0), Col("f", "char", 0)]
+    data = b"".join(b"<d>%s</d><f>%s</f><endl/>\n" % (v.encode(), v.encode()) for v in vals)
+    got = gpu_xml(data, cols, typed=[5, 6], carry=False)
+    exp = port.parse_xml(data, cols, typed=[5, 6], carry=False)
+    assert_batches_equal(got, exp, "long numeric")
 
 
 def test_parse_file_and_accessors(tmp_path, port):
