@@ -48,6 +48,16 @@ def build_parse(force=False):
     return target
 
 
+def build_diag(force=True):
+    """Diagnostic variant with per-phase cycle counters (never used by tests or bench)."""
+    target = os.path.join(HERE, "libmdc_parse_diag.so")
+    srcs = [os.path.join(CSRC, f) for f in ("mdc_kernels.hip", "mdc_abi.cpp")]
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    _run([hipcc] + HIPCC_FLAGS + ["-DMDC_PHASE_TIMING", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+                                  "-x", "hip"] + srcs + ["-o", target])
+    return target
+
+
 def build_gen(force=False):
     target = os.path.join(HERE, "libmdc_gen.so")
     src = os.path.join(CSRC, "mdc_gen.c")

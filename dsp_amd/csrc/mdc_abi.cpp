@@ -196,16 +196,16 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         uint32_t o = 0;
         L.data = o;
         o += round16(TILE + LBMAX + DATA_SLACK);
+        L.evlist = o;
+        L.evcap = 3072;
+        L.stage_cap = L.evcap * 4;
+        o += L.evcap * 4;
         L.evt = o;
-        o += round16(RB * (npat > ncols ? npat : ncols) * 4);
-        L.dstart = o;
+        o += round16(RB * npat * 4);
+        L.desc = o;
         o += round16(RB * ncols * 4);
-        L.dlen = o;
-        o += round16(RB * ncols * 4);
-        L.cterm = o;
-        o += round16(NCH * 2);
-        L.cpre = o;
-        o += round16(NCH * 2);
+        L.olen = o;
+        o += round16(RB * ncols * 4 + 4);
         L.recend = o;
         o += round16((RB + 1) * 4);
         L.vmask = o;
@@ -218,10 +218,6 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         o += round16(blob_bytes);
         L.misc = o;
         o += 256;
-        L.stage = o;
-        uint32_t stage_cap = 8192;
-        o += stage_cap;
-        L.stage_cap = stage_cap;
         L.total = o;
         L.RB = RB;
         if (o <= 80 * 1024 || RB <= 8) break;
@@ -251,6 +247,7 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
     if (memchr(endbz, '\n', el)) return fail(MDC_ERR_ARG, "endbz must not contain a newline");
     H->endbz_len = (uint32_t)el;
     memcpy(H->endbz, endbz, el);
+    if (el <= 8) memcpy(H->endbz_tail + 8 - el, endbz, el);
     if (p->mode == MODE_CSV) {
         size_t sl = strlen(sep);
         if (sl == 0 || sl > MAX_SEP) return fail(MDC_ERR_ARG, "separator must be 1..%d bytes", MAX_SEP);
@@ -315,6 +312,7 @@ static int parser_finish(mdc_parser *p, const mdc_opts *opts) {
     rc = dev_alloc(p->dev, 256, &st);
     if (rc) return rc;
     p->d_status = (uint32_t *)st;
+    HIP_TRY(hipMemset(p->d_status, 0, 256));
     HIP_TRY(hipHostMalloc((void **)&p->h_totals, (MAX_COLS + 8) * sizeof(uint64_t), hipHostMallocDefault));
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&p->ev[i]));
     return MDC_OK;
@@ -633,6 +631,16 @@ extern "C" int mdc_parse_file(mdc_parser *p, const char *path, mdc_batch **out) 
     if (bad) return fail(MDC_ERR_IO, "read(%s) failed", path);
     return mdc_parse_host(p, buf.data(), buf.size(), out);
 }
+
+#ifdef MDC_PHASE_TIMING
+// diagnostic build only: cycle counters behind the status word (see STAMP in the kernels)
+extern "C" int mdc_debug_phase_counters(mdc_parser *p, unsigned long long *out, int n, int reset) {
+    HIP_TRY(hipSetDevice(p->dev->id));
+    HIP_TRY(hipMemcpy(out, (unsigned long long *)p->d_status + 2, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset((unsigned long long *)p->d_status + 2, 0, (size_t)n * 8));
+    return MDC_OK;
+}
+#endif
 
 extern "C" int mdc_parser_last_timing(const mdc_parser *p, mdc_timing *t) {
     if (!p || !t) return fail(MDC_ERR_ARG, "NULL argument");

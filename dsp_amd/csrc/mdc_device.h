@@ -14,8 +14,6 @@ constexpr int BLOCK = 256;
 constexpr int TILE = 16384;
 constexpr int LBMAX = 8192;
 constexpr int CHUNK = 16;                                // bytes per lane per step (one dwordx4)
-constexpr int NCH = (TILE + LBMAX) / CHUNK;              // chunks in the LDS image
-constexpr int CPT = NCH / BLOCK;                         // chunks per thread in the rank scan
 constexpr int DATA_SLACK = 64;                           // readable bytes past the image
 constexpr int LB_FIRST = 512;                            // first look-behind window
 constexpr int LB_STEP = BLOCK * CHUNK;                   // later windows
@@ -24,7 +22,8 @@ constexpr int MAX_ENDBZ = 32;
 constexpr int MAX_SEP = 16;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
-static_assert(NCH % BLOCK == 0, "chunk count must divide evenly over the block");
+static_assert(TILE == BLOCK * 64, "every lane owns 64 tile bytes");
+static_assert(TILE + LBMAX + 64 <= 32768, "cell descriptors hold 15-bit LDS indices");
 
 // filter level of a cell: nested projections char (everything) > number > date
 enum : uint8_t { LVL_CHAR = 0, LVL_NUMBER = 1, LVL_DATE = 2 };
@@ -73,6 +72,8 @@ struct SchemaHdr {
     uint32_t bdelspace, any_typed, r1, r2;
     uint8_t endbz[MAX_ENDBZ];
     uint8_t sep[MAX_SEP];
+    uint8_t endbz_tail[8];  // endbz right-aligned in 8 bytes (when endbz_len <= 8)
+    uint8_t pad8[8];
     // followed by DevCol[ncols], then HtEntry[ht_mask+1] (16-byte aligned)
 };
 static_assert(sizeof(SchemaHdr) % 16 == 0, "SchemaHdr must keep 16-byte alignment");
@@ -80,21 +81,20 @@ static_assert(sizeof(SchemaHdr) % 16 == 0, "SchemaHdr must keep 16-byte alignmen
 // byte offsets of the LDS regions (computed on the host from the schema)
 struct LdsLayout {
     uint32_t data;    // TILE+LBMAX+DATA_SLACK bytes
-    uint32_t evt;     // RB*npat u32 (first positions); reused as per-cell lengths/offsets
-    uint32_t dstart;  // RB*ncols u32
-    uint32_t dlen;    // RB*ncols u32 (level in bits 30..31)
-    uint32_t cterm;   // NCH u16: terminator bit mask per chunk
-    uint32_t cpre;    // NCH u16: terminators in front of the chunk
+    uint32_t evlist;  // evcap u32: dense list of '<' events (position | rank<<16); later the cell staging area
+    uint32_t evt;     // RB*npat u32: first position of every tag pattern per record
+    uint32_t desc;    // RB*ncols u32: cell descriptors
+    uint32_t olen;    // RB*ncols u32: cell lengths, then exclusive offsets
     uint32_t recend;  // (RB+1) u32
     uint32_t vmask;   // RB*words u32
     uint32_t fmask;   // RB*words u32
     uint32_t coltot;  // 3*(ncols+1) u32: batch totals, tile totals, stage bases
-    uint32_t stage;   // stage_cap bytes
     uint32_t schema;  // schema blob
-    uint32_t misc;    // 64 u32 of block-wide scalars
+    uint32_t misc;    // block-wide scalars
     uint32_t total;
-    uint32_t RB;         // records per batch
-    uint32_t stage_cap;
+    uint32_t RB;         // records per batch (<= 256)
+    uint32_t evcap;      // events per compaction window
+    uint32_t stage_cap;  // = evcap*4
 };
 
 struct TileParams {

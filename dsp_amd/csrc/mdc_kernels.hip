@@ -3,21 +3,23 @@
 // One workgroup (256 threads = 4 wave64) per TILE input bytes.  A tile owns the records
 // whose terminating '\n' lies inside it.  Per tile:
 //
-//   0. stage [tile_start-LB, tile_end) into LDS with 16-byte loads; LB grows backwards until
-//      the terminator in front of the tile is found (look-behind, normally one 512-byte step)
-//   1. every lane classifies its 16-byte chunks with SWAR compares: record terminators
-//      ('\n' preceded by endbz, cifile::readline, reference public/_public.cpp:866-892);
-//      a block-wide prefix sum of the per-chunk counts ranks every byte by record
-//   2. every '<' is looked up in a hash table of the schema's tag texts held in LDS; a hit
-//      does an LDS atomicMin on first_pos[pattern][record]: the independent first-open /
-//      first-close search of getxmlbuffer (public/_public.cpp:466,469).  Delimited mode marks
-//      separator candidates instead (ccmdstr::splittocmd, public/_public.cpp:283-292)
-//   3. one lane per record resolves the columns in schema order (clip, negative length,
-//      carry-forward: tools/xmltodb.cpp:492-522) into (start,len,filter level) descriptors
-//   4. one lane per cell filters (picknumber, public/_public.cpp:178-204), measures and
-//      converts (mdc_numparse.h) its cell
-//   5. per-column prefix sums give every cell its offset; cells are compacted into an LDS
-//      staging area that mirrors the destination's 16-byte phase and leave with 16-byte stores
+//   A. every lane loads 64 consecutive tile bytes (4 x dwordx4) into registers and LDS; a
+//      512-byte look-behind window in front of the tile is staged with them and grows
+//      backwards only when the terminator in front of the tile is not inside it
+//   B. SWAR compares on the registers give 64-bit masks of '\n' and '<'; a '\n' preceded by
+//      endbz is a record terminator (cifile::readline, reference public/_public.cpp:866-892);
+//      one packed block-wide prefix sum ranks every byte by record and numbers the '<' events
+//   C. the '<' positions are compacted into a dense LDS list (position | record rank)
+//   D. one lane per event: an unaligned 8-byte LDS read is the key into a hash table of the
+//      schema's tag texts; a hit does an LDS atomicMin on first_pos[pattern][record]: the
+//      independent first-open / first-close search of getxmlbuffer (public/_public.cpp:466,469)
+//   E. one lane per cell: clip, negative length and carry-forward (tools/xmltodb.cpp:492-522),
+//      then picknumber's filter (public/_public.cpp:178-204), the cell length and the typed
+//      value (mdc_numparse.h), on 16 source bytes held in registers
+//   F. per-column prefix sums give every cell its offset
+//   G. cells are compacted into an LDS staging area that mirrors the destination's 16-byte
+//      phase and leave with 16-byte stores; delimited mode resolves its fields with one lane
+//      per record (ccmdstr::splittocmd, public/_public.cpp:274-302) in place of C/D
 //
 // The kernel runs twice per parse: COUNT mode stops after step 4 and reports per-tile byte
 // and row counts; a scan turns them into tile base offsets; WRITE mode repeats the (fully
@@ -58,71 +60,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
         if (lane >= d) v += t;
     }
     return v;
-}
-
-struct Ctx {
-    uint8_t *sdata;
-    const SchemaHdr *H;
-    const DevCol *cols;
-    const HtEntry *ht;
-    const uint8_t *gdata;
-    int64_t base_pos;  // global position of LDS index 0 (may be negative)
-};
-
-// byte at LDS index li, reading global memory below the staged region
-__device__ __forceinline__ uint32_t byte_at(const Ctx &cx, int li, int loaded_lo) {
-    return li >= loaded_lo ? cx.sdata[li] : cx.gdata[cx.base_pos + li];
-}
-
-// is the '\n' at LDS index p_li a record terminator, i.e. preceded by endbz?
-__device__ __forceinline__ bool is_terminator(const Ctx &cx, int p_li, int loaded_lo) {
-    const int el = (int)cx.H->endbz_len;
-    if (el == 0) return true;
-    if (cx.base_pos + p_li - el < 0) return false;
-    for (int k = 0; k < el; ++k)
-        if (byte_at(cx, p_li - el + k, loaded_lo) != cx.H->endbz[k]) return false;
-    return true;
-}
-
-// Looks up the tag text that follows the '<' at LDS index q and records a first-position
-// event for every (column, open/close) pattern with that text.
-__device__ __forceinline__ void match_tag(const Ctx &cx, uint32_t q, uint32_t *evt, uint32_t rl, uint32_t RB) {
-    const uint32_t *s32 = (const uint32_t *)cx.sdata;
-    const uint32_t a = q + 1;
-    const uint32_t wi = a >> 2, sh = a & 3;
-    const uint32_t w0 = s32[wi], w1 = s32[wi + 1], w2 = s32[wi + 2];
-    uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
-    uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-    // position of the first '>' among the eight bytes
-    const uint32_t glo = bytes_eq(lo, 0x3E3E3E3Eu), ghi = bytes_eq(hi, 0x3E3E3E3Eu);
-    if (glo) {
-        const uint32_t g = (uint32_t)__builtin_ctz(glo) >> 3;  // 0..3
-        lo &= 0xFFFFFFFFu >> (8 * (3 - g));
-        hi = 0;
-    } else if (ghi) {
-        const uint32_t g = (uint32_t)__builtin_ctz(ghi) >> 3;
-        hi &= 0xFFFFFFFFu >> (8 * (3 - g));
-    }
-    uint32_t slot = ht_hash(lo, hi) & cx.H->ht_mask;
-    for (;;) {
-        const HtEntry e = cx.ht[slot];
-        if (!(e.meta >> 31)) break;
-        if (e.klo == lo && e.khi == hi) {
-            const uint32_t tlen = e.meta & 0xFFu, kind = (e.meta >> 8) & 1u, col = (e.meta >> 16) & 0x7FFFu;
-            bool ok = true;
-            if (tlen >= 8) {  // texts of 8+ bytes share their key with longer ones: compare the tail
-                const uint8_t *nm = cx.cols[col].name;
-                for (uint32_t k = 8; k < tlen; ++k)
-                    if (cx.sdata[a + k] != nm[k - kind]) {
-                        ok = false;
-                        break;
-                    }
-                if (ok && cx.sdata[a + tlen] != '>') ok = false;
-            }
-            if (ok) atomicMin(&evt[(2 * col + kind) * RB + rl], q);
-        }
-        slot = (slot + 1) & cx.H->ht_mask;
-    }
 }
 
 // Walks the bytes of one cell's source through the cell's filter.  EMIT=false measures the
@@ -178,100 +115,268 @@ __device__ __forceinline__ uint32_t cell_walk(const uint8_t *src, uint32_t len, 
     return out;
 }
 
+// Diagnostic build only (-DMDC_PHASE_TIMING): thread 0 of every block adds the cycles spent
+// since the previous stamp to a per-phase counter that sits behind the status word.  The
+// counters are read by nothing in the kernel.
+#ifdef MDC_PHASE_TIMING
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        if (threadIdx.x == 0) {                                                                    \
+            const unsigned long long now_ = __builtin_readcyclecounter();                          \
+            atomicAdd(((unsigned long long *)P.status) + 2 + (i), now_ - stamp_t_);                \
+            stamp_t_ = now_;                                                                       \
+        }                                                                                          \
+    } while (0)
+#define STAMP_INIT unsigned long long stamp_t_ = __builtin_readcyclecounter()
+#else
+#define STAMP(i) \
+    do {         \
+    } while (0)
+#define STAMP_INIT \
+    do {           \
+    } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------
 // indices of the block-wide scalars kept in LDS
-enum { MS_LAST = 0, MS_NREC = 1, MS_HASNUL = 2, MS_STAGED = 3, MS_WTOT = 4 /* 4 words */, MS_COUNT = 16 };
+enum {
+    MS_LAST = 0,    // look-behind: LDS index of the last terminator in front of the tile
+    MS_HASNUL = 1,
+    MS_STAGED = 2,
+    MS_LBCNT = 3,   // events found in the look-behind region
+    MS_WTOT = 4,    // 4 words: per-wave totals of the rank/event scan
+    MS_COUNT = 16
+};
+
+// unaligned LDS reads (gfx950 honours byte-unaligned ds_read_b64/b128)
+__device__ __forceinline__ uint64_t lds_u64(const uint8_t *p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ uint4 lds_u128(const uint8_t *p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+// 64-bit byte-equality mask of the 64 bytes held in four dwordx4 registers
+__device__ __forceinline__ uint64_t mask64_eq(const uint4 (&v)[4], uint32_t pat4) {
+    const uint64_t lo = (uint64_t)mask16_eq(v[0], pat4) | ((uint64_t)mask16_eq(v[1], pat4) << 16);
+    const uint64_t hi = (uint64_t)mask16_eq(v[2], pat4) | ((uint64_t)mask16_eq(v[3], pat4) << 16);
+    return lo | (hi << 32);
+}
+
+// is the '\n' at LDS index p a record terminator (preceded by endbz)?  All bytes involved are
+// staged: the look-behind always covers at least MAX_ENDBZ bytes in front of the tile.
+__device__ __forceinline__ bool is_term(const uint8_t *sdata, const SchemaHdr *H, int64_t base_pos, int p) {
+    const int el = (int)H->endbz_len;
+    if (el == 0) return true;
+    if (base_pos + p - el < 0) return false;
+    if (el <= 8) {
+        const uint64_t w = lds_u64(sdata + p - 8), want = *(const uint64_t *)H->endbz_tail;
+        const uint64_t m = ~0ull << (8 * (8 - el));
+        return ((w ^ want) & m) == 0;
+    }
+    for (int k = 0; k < el; ++k)
+        if (sdata[p - el + k] != H->endbz[k]) return false;
+    return true;
+}
+
+// Tag lookup for the '<' at LDS index q: one unaligned 8-byte read gives the key, the hash
+// table is probed until an empty slot; each hit lowers first_pos[pattern][record].
+__device__ __forceinline__ void match_tag(const uint8_t *sdata, const SchemaHdr *H, const DevCol *cols,
+                                          const HtEntry *ht, uint32_t q, uint32_t *evt, uint32_t rl, uint32_t RB) {
+    const uint32_t a = q + 1;
+    const uint64_t w = lds_u64(sdata + a);
+    uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+    const uint32_t glo = bytes_eq(lo, 0x3E3E3E3Eu), ghi = bytes_eq(hi, 0x3E3E3E3Eu);
+    if (glo) {
+        const uint32_t g = (uint32_t)__builtin_ctz(glo) >> 3;
+        lo &= 0xFFFFFFFFu >> (8 * (3 - g));
+        hi = 0;
+    } else if (ghi) {
+        const uint32_t g = (uint32_t)__builtin_ctz(ghi) >> 3;
+        hi &= 0xFFFFFFFFu >> (8 * (3 - g));
+    }
+    uint32_t slot = ht_hash(lo, hi) & H->ht_mask;
+    for (;;) {
+        const HtEntry e = ht[slot];
+        if (!(e.meta >> 31)) break;
+        if (e.klo == lo && e.khi == hi) {
+            const uint32_t tlen = e.meta & 0xFFu, kind = (e.meta >> 8) & 1u, col = (e.meta >> 16) & 0x7FFFu;
+            bool ok = true;
+            if (tlen >= 8) {  // texts of 8+ bytes share their key with longer ones: compare the tail
+                const uint8_t *nm = cols[col].name;
+                for (uint32_t k = 8; k < tlen; ++k)
+                    if (sdata[a + k] != nm[k - kind]) {
+                        ok = false;
+                        break;
+                    }
+                if (ok && sdata[a + tlen] != '>') ok = false;
+            }
+            if (ok) atomicMin(&evt[(2 * col + kind) * RB + rl], q);
+        }
+        slot = (slot + 1) & H->ht_mask;
+    }
+}
+
+// Register-resident variant of cell_walk for cells of at most 16 source bytes (lo = bytes
+// 0..7, hi = bytes 8..15 of the source).
+template <bool EMIT>
+__device__ __forceinline__ uint32_t cell_walk16(uint64_t lo, uint64_t hi, uint32_t len, uint32_t lvl, bool nulcut,
+                                               uint32_t typed, uint8_t *dst, uint64_t &value, bool &valid,
+                                               bool &range) {
+    uint32_t out = 0;
+    NumAcc acc;
+    bool boolok = true;
+    const bool isfloat = (typed == T_F64 || typed == T_F32);
+    const bool issigned = (typed == T_I32 || typed == T_I64 || isfloat);
+    if (!EMIT) num_init(acc);
+    for (uint32_t k = 0; k < len; ++k) {
+        const uint32_t b = (uint32_t)lo & 0xFFu;
+        lo = (lo >> 8) | (hi << 56);
+        hi >>= 8;
+        const bool dig = (b - '0') < 10u;
+        const bool sgn = (b == '+') | (b == '-');
+        const bool dot = (b == '.');
+        bool pass;
+        if (lvl == LVL_CHAR) {
+            if (nulcut && b == 0) break;
+            pass = true;
+        } else if (lvl == LVL_NUMBER) {
+            pass = dig | sgn | dot;
+        } else {
+            pass = dig;
+        }
+        if (!pass) continue;
+        if (EMIT) {
+            dst[out] = (uint8_t)b;
+        } else if (typed != T_NONE) {
+            if (typed == T_BOOL) {
+                const uint32_t u = (b >= 'a' && b <= 'z') ? b - 32 : b;
+                const uint32_t want = out == 0 ? 'T' : out == 1 ? 'R' : out == 2 ? 'U' : out == 3 ? 'E' : 0x100;
+                boolok = boolok && (u == want);
+            } else if (dig | (issigned & sgn) | (isfloat & dot)) {
+                num_feed(acc, b, isfloat);
+            }
+        }
+        ++out;
+    }
+    if (!EMIT && typed != T_NONE) {
+        if (typed == T_BOOL) {
+            valid = true;
+            value = (boolok && out == 4) ? 1 : 0;
+        } else {
+            uint64_t v = 0;
+            valid = num_finish(acc, typed, v, range);
+            value = valid ? v : 0;
+        }
+    }
+    return out;
+}
+
+// descriptor of one cell: source start (15 bits) | source length (15 bits) | filter level (2)
+__device__ __forceinline__ uint32_t desc_pack(uint32_t start, uint32_t len, uint32_t lvl) {
+    return start | (len << 15) | (lvl << 30);
+}
 
 template <bool WRITE>
 __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     const LdsLayout &L = P.L;
     uint8_t *sdata = smem + L.data;
+    uint32_t *evlist = (uint32_t *)(smem + L.evlist);
     uint32_t *evt = (uint32_t *)(smem + L.evt);
-    uint32_t *olen = evt;  // evt is dead once the descriptors exist
-    uint32_t *dstart = (uint32_t *)(smem + L.dstart);
-    uint32_t *dlen = (uint32_t *)(smem + L.dlen);
-    uint16_t *cterm = (uint16_t *)(smem + L.cterm);
-    uint16_t *cpre = (uint16_t *)(smem + L.cpre);
+    uint32_t *olen = (uint32_t *)(smem + L.olen);
+    uint32_t *desc = (uint32_t *)(smem + L.desc);
     uint32_t *recend = (uint32_t *)(smem + L.recend);
     uint32_t *vmask = (uint32_t *)(smem + L.vmask);
     uint32_t *fmask = (uint32_t *)(smem + L.fmask);
-    uint8_t *stage = smem + L.stage;
-    volatile uint32_t *ms = (volatile uint32_t *)(smem + L.misc);
-    uint32_t *msa = (uint32_t *)(smem + L.misc);
+    uint8_t *stage = smem + L.evlist;  // the event list is dead when cells are staged
+    uint32_t *ms = (uint32_t *)(smem + L.misc);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-
-    // ---- schema blob -> LDS
-    {
-        const uint4 *g = (const uint4 *)P.schema;
-        uint4 *s = (uint4 *)(smem + L.schema);
-        for (uint32_t i = tid; i < P.schema_bytes / 16; i += BLOCK) s[i] = g[i];
-        if (tid < MS_COUNT) msa[tid] = 0;
-        if (tid == 0) msa[MS_LAST] = NONE;
-    }
-    __syncthreads();
-    Ctx cx;
-    cx.sdata = sdata;
-    cx.H = (const SchemaHdr *)(smem + L.schema);
-    cx.cols = (const DevCol *)(cx.H + 1);
-    const uint32_t ncols = cx.H->ncols, npat = cx.H->npat, W = cx.H->words;
-    cx.ht = (const HtEntry *)((const uint8_t *)cx.cols + ((ncols * sizeof(DevCol) + 15) & ~15u));
-    cx.gdata = P.data;
-    const bool csv = cx.H->mode == MODE_CSV;
-    const bool carry = cx.H->carry != 0;
-    uint32_t *coltot = (uint32_t *)(smem + L.coltot);  // totals of the current batch
-    uint32_t *tiletot = coltot + (ncols + 1);          // totals of the batches done so far
-    uint32_t *stagebase = tiletot + (ncols + 1);
+    STAMP_INIT;
 
     const int64_t n = (int64_t)P.n;
     const int64_t tile_start = (int64_t)blockIdx.x * TILE;
     const int64_t tile_end = (tile_start + TILE < n) ? tile_start + TILE : n;
-    cx.base_pos = tile_start - LBMAX;
+    const int64_t base_pos = tile_start - LBMAX;  // global position of LDS index 0
     const int ts_li = LBMAX;
     const int te_li = LBMAX + (int)(tile_end - tile_start);
-    const int li_min = cx.base_pos < 0 ? (int)(-cx.base_pos) : 0;
+    const int li_min = base_pos < 0 ? (int)(-base_pos) : 0;
 
-    auto load_chunks = [&](int jlo, int jhi) {
-        for (int j = jlo + tid; j < jhi; j += BLOCK) {
-            const int64_t pos = cx.base_pos + (int64_t)j * CHUNK;
-            uint4 v;
-            if (pos + CHUNK <= n) {
-                v = *(const uint4 *)(P.data + pos);
-            } else {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (int k = 0; k < CHUNK; ++k)
-                    if (pos + k < n) w[k >> 2] |= (uint32_t)P.data[pos + k] << (8 * (k & 3));
-                v = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            ((uint4 *)sdata)[j] = v;
-        }
+    auto load_chunk = [&](int j) -> uint4 {  // 16-byte chunk j of the LDS image, from global memory
+        const int64_t pos = base_pos + (int64_t)j * CHUNK;
+        if (pos + CHUNK <= n) return *(const uint4 *)(P.data + pos);
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int k = 0; k < CHUNK; ++k)
+            if (pos + k < n) w[k >> 2] |= (uint32_t)P.data[pos + k] << (8 * (k & 3));
+        return make_uint4(w[0], w[1], w[2], w[3]);
     };
 
-    if (tid < (int)ncols + 1) tiletot[tid] = 0;
+    // ---- A. this lane's 64 tile bytes -> registers and LDS; first look-behind window; schema
+    uint4 v[4];
+    {
+        const int jb = ts_li / CHUNK + tid * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (jb + k) * CHUNK < te_li ? load_chunk(jb + k) : make_uint4(0, 0, 0, 0);
+    }
+    int loaded_lo = ts_li;
+    if (tile_start > 0) {
+        loaded_lo = ts_li - LB_FIRST < li_min ? li_min : ts_li - LB_FIRST;
+        const int j = loaded_lo / CHUNK + tid;
+        if (j < ts_li / CHUNK) ((uint4 *)sdata)[j] = load_chunk(j);
+    }
+    {
+        const uint4 *g = (const uint4 *)P.schema;
+        uint4 *s = (uint4 *)(smem + L.schema);
+        for (uint32_t i = tid; i < P.schema_bytes / 16; i += BLOCK) s[i] = g[i];
+        if (tid < MS_COUNT) ms[tid] = tid == MS_LAST ? NONE : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ((uint4 *)sdata)[ts_li / CHUNK + tid * 4 + k] = v[k];
+    }
+    __syncthreads();
+    const SchemaHdr *H = (const SchemaHdr *)(smem + L.schema);
+    const DevCol *cols = (const DevCol *)(H + 1);
+    const uint32_t ncols = H->ncols, npat = H->npat, W = H->words;
+    const HtEntry *ht = (const HtEntry *)((const uint8_t *)cols + ((ncols * sizeof(DevCol) + 15) & ~15u));
+    const bool csv = H->mode == MODE_CSV;
+    const bool carry = H->carry != 0;
+    uint32_t *coltot = (uint32_t *)(smem + L.coltot);  // totals of the current batch
+    uint32_t *tiletot = coltot + (ncols + 1);          // totals of the batches done so far
+    uint32_t *stagebase = tiletot + (ncols + 1);
     for (uint32_t c = tid; c < ncols + 1; c += BLOCK) tiletot[c] = 0;
 
-    // ---- 0. stage the tile, then look behind for the start of the first owned record
-    const int j1 = (te_li + CHUNK - 1) / CHUNK;
-    load_chunks(ts_li / CHUNK, j1);
-    int loaded_lo = ts_li;
+    // look behind for the start of the first owned record
     int s0_li = ts_li;
     if (tile_start > 0) {
-        int win = LB_FIRST;
+        int new_lo = loaded_lo;
+        int hi_li = ts_li;
         for (;;) {
-            int new_lo = loaded_lo - win;
-            if (new_lo < li_min) new_lo = li_min;
-            load_chunks(new_lo / CHUNK, loaded_lo / CHUNK);
-            __syncthreads();
-            for (int j = new_lo / CHUNK + tid; j < loaded_lo / CHUNK; j += BLOCK) {
-                const uint4 v = ((const uint4 *)sdata)[j];
-                uint32_t nl = mask16_eq(v, 0x0A0A0A0Au);
+            for (int j = new_lo / CHUNK + tid; j < hi_li / CHUNK; j += BLOCK) {
+                const uint4 c4 = ((const uint4 *)sdata)[j];
+                uint32_t nl = mask16_eq(c4, 0x0A0A0A0Au);
                 while (nl) {
                     const int b = __builtin_ctz(nl);
                     nl &= nl - 1;
                     const int p = j * CHUNK + b;
-                    if (is_terminator(cx, p, new_lo)) atomicMax((int *)&msa[MS_LAST], p);
+                    // endbz bytes below the staged region are read from global memory
+                    bool t;
+                    if (p - (int)H->endbz_len >= new_lo) {
+                        t = is_term(sdata, H, base_pos, p);
+                    } else {
+                        const int el = (int)H->endbz_len;
+                        t = base_pos + p - el >= 0;
+                        for (int k = 0; t && k < el; ++k) {
+                            const int li = p - el + k;
+                            const uint32_t bb = li >= new_lo ? sdata[li] : P.data[base_pos + li];
+                            t = bb == H->endbz[k];
+                        }
+                    }
+                    if (t) atomicMax((int *)&ms[MS_LAST], p);
                 }
             }
             __syncthreads();
@@ -281,7 +386,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 s0_li = last + 1;
                 break;
             }
-            if (cx.base_pos + new_lo == 0) {  // reached the start of the input
+            if (base_pos + new_lo == 0) {  // reached the start of the input
                 s0_li = new_lo;
                 break;
             }
@@ -290,57 +395,54 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 s0_li = 0;
                 break;
             }
-            win = LB_STEP;
+            hi_li = new_lo;
+            new_lo = hi_li - LB_STEP < li_min ? li_min : hi_li - LB_STEP;
+            for (int j = new_lo / CHUNK + tid; j < hi_li / CHUNK; j += BLOCK) ((uint4 *)sdata)[j] = load_chunk(j);
+            __syncthreads();
         }
-    } else {
-        __syncthreads();
     }
-    const int j0 = s0_li / CHUNK;
+    STAMP(0);  // load + look-behind
 
-    // ---- 1. terminators per chunk, NUL presence, rank prefix
+    // ---- B. classify the lane's 64 bytes: terminators, '<' (or separator starts), NUL
+    const int my_li = ts_li + tid * 64;
+    uint64_t tm = 0;   // record terminators
+    uint64_t em;       // event candidates: '<' in XML mode (delimited mode does not use events)
     {
-        bool nul = false;
-        for (int j = tid; j < NCH; j += BLOCK) {
-            uint32_t tm = 0;
-            if (j >= j0 && j < j1) {
-                const uint4 v = ((const uint4 *)sdata)[j];
-                nul |= mask16_eq(v, 0) != 0;
-                uint32_t nl = mask16_eq(v, 0x0A0A0A0Au);
-                while (nl) {
-                    const int b = __builtin_ctz(nl);
-                    nl &= nl - 1;
-                    const int p = j * CHUNK + b;
-                    if (p >= ts_li && p < te_li && is_terminator(cx, p, loaded_lo)) tm |= 1u << b;
-                }
-            }
-            cterm[j] = (uint16_t)tm;
+        uint64_t nlm = mask64_eq(v, 0x0A0A0A0Au);
+        em = csv ? 0 : mask64_eq(v, 0x3C3C3C3Cu);
+        if (mask64_eq(v, 0)) ms[MS_HASNUL] = 1;
+        const int lim = te_li - my_li;  // bytes of this lane that belong to the input
+        if (lim < 64) {
+            const uint64_t keep = lim <= 0 ? 0 : (~0ull >> (64 - lim));
+            nlm &= keep;
+            em &= keep;
         }
-        if (nul) msa[MS_HASNUL] = 1;
+        while (nlm) {
+            const int b = __builtin_ctzll(nlm);
+            nlm &= nlm - 1;
+            if (is_term(sdata, H, base_pos, my_li + b)) tm |= 1ull << b;
+        }
     }
-    __syncthreads();
+    uint32_t rank_base, ev_base, nrec, nev_tile;
     {
-        uint32_t cnt[CPT], sum = 0;
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            cnt[k] = __builtin_popcount(cterm[tid * CPT + k]);
-            sum += cnt[k];
-        }
-        const uint32_t incl = wave_incl_scan(sum);
-        if (lane == 63) msa[MS_WTOT + wave] = incl;
+        const uint32_t mine = ((uint32_t)__builtin_popcountll(tm) << 16) | (uint32_t)__builtin_popcountll(em);
+        const uint32_t incl = wave_incl_scan(mine);
+        if (lane == 63) ms[MS_WTOT + wave] = incl;
         __syncthreads();
-        uint32_t base = incl - sum;
-        for (int w = 0; w < wave; ++w) base += ms[MS_WTOT + w];
+        uint32_t base = incl - mine, tot = 0;
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            cpre[tid * CPT + k] = (uint16_t)base;
-            base += cnt[k];
+        for (int w = 0; w < BLOCK / 64; ++w) {
+            const uint32_t t = ms[MS_WTOT + w];
+            if (w < wave) base += t;
+            tot += t;
         }
-        if (tid == BLOCK - 1) msa[MS_NREC] = base;
+        rank_base = base >> 16;
+        ev_base = base & 0xFFFFu;
+        nrec = tot >> 16;
+        nev_tile = tot & 0xFFFFu;
     }
-    __syncthreads();
-    const uint32_t nrec = ms[MS_NREC];
     const bool has_nul = ms[MS_HASNUL] != 0;
-    const uint32_t RB = L.RB;
+    const uint32_t RB = L.RB, EVCAP = L.evcap;
     const uint64_t *tb = WRITE ? P.tile_base + (uint64_t)blockIdx.x * (ncols + 1) : nullptr;
     const uint64_t row0 = WRITE ? tb[ncols] : 0;
     if (WRITE && blockIdx.x == 0) {
@@ -348,7 +450,9 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         for (uint32_t c = tid; c < ncols; c += BLOCK) P.off[c][0] = 0;
     }
     if (tid == 0) recend[0] = (uint32_t)(s0_li - 1);
-    const uint32_t seplen = cx.H->sep_len;
+    const uint32_t seplen = H->sep_len;
+    const int jlb0 = s0_li / CHUNK, jlb1 = ts_li / CHUNK;  // look-behind chunks of the first record
+    STAMP(1);  // classify + rank scan
 
     // ---- batches of RB records
     for (uint32_t rb0 = 0; rb0 < nrec; rb0 += RB) {
@@ -358,86 +462,81 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             vmask[i] = 0;
             fmask[i] = 0;
         }
-        __syncthreads();
-
-        // ---- 2. events
-        for (int j = j0 + tid; j < j1; j += BLOCK) {
-            const uint32_t rank0 = cpre[j];
-            const uint32_t tm = cterm[j];
-            const uint32_t cnt = __builtin_popcount(tm);
-            if (rank0 + cnt < rb0 || rank0 >= rb0 + RBn) continue;
-            uint32_t t = tm;
+        // terminator positions of this batch
+        {
+            uint64_t t = tm;
+            uint32_t r = rank_base;
             while (t) {
-                const uint32_t b = __builtin_ctz(t);
+                const int b = __builtin_ctzll(t);
                 t &= t - 1;
-                const uint32_t r = rank0 + __builtin_popcount(tm & ((1u << b) - 1));
-                if (r >= rb0 && r < rb0 + RBn) recend[r - rb0 + 1] = (uint32_t)(j * CHUNK) + b;
-            }
-            if (!csv) {
-                const uint4 v = ((const uint4 *)sdata)[j];
-                uint32_t m = mask16_eq(v, 0x3C3C3C3Cu);
-                while (m) {
-                    const uint32_t b = __builtin_ctz(m);
-                    m &= m - 1;
-                    const uint32_t q = (uint32_t)(j * CHUNK) + b;
-                    if ((int)q < s0_li) continue;
-                    const uint32_t r = rank0 + __builtin_popcount(tm & ((1u << b) - 1));
-                    if (r < rb0 || r >= rb0 + RBn) continue;
-                    match_tag(cx, q, evt, r - rb0, RB);
-                }
+                if (r >= rb0 && r < rb0 + RBn) recend[r - rb0 + 1] = (uint32_t)(my_li + b);
+                ++r;
             }
         }
         __syncthreads();
+        STAMP(2);  // clears
 
-        // ---- 3. one lane per record: columns in schema order
-        if ((uint32_t)tid < RBn) {
-            const uint32_t r = tid;
-            const uint32_t rs = recend[r] + 1, re = recend[r + 1];
-            uint32_t fmw = 0;
-            if (!csv) {
-                uint32_t cur_s = rs, cur_l = 0, lvl = LVL_CHAR;
-                for (uint32_t c = 0; c < ncols; ++c) {
-                    const uint32_t o = evt[(2 * c) * RB + r], e = evt[(2 * c + 1) * RB + r];
-                    const DevCol &col = cx.cols[c];
-                    if (o != NONE && e != NONE) {
-                        const uint32_t vs = o + col.namelen + 2;
-                        int len = (int)e - (int)vs;
-                        if (len < 0)
-                            len = (int)(re - vs);  // close tag in front of the open tag: rest of record
-                        else if (col.collen > 0 && col.collen < len)
-                            len = col.collen;
-                        cur_s = vs;
-                        cur_l = (uint32_t)len;
-                        lvl = LVL_CHAR;
-                        fmw |= 1u << (c & 31);
-                    } else if (!carry) {
-                        cur_l = 0;
-                        lvl = LVL_CHAR;
-                    }
-                    if (col.level > lvl) lvl = col.level;
-                    dstart[c * RB + r] = cur_s;
-                    dlen[c * RB + r] = cur_l | (lvl << 30);
-                    if ((c & 31) == 31 || c + 1 == ncols) {
-                        fmask[r * W + (c >> 5)] = fmw;
-                        fmw = 0;
+        if (!csv) {
+            // ---- C. the first record's events in the look-behind region (first batch only)
+            if (rb0 == 0) {
+                for (int j = jlb0 + tid; j < jlb1; j += BLOCK) {
+                    const uint4 c4 = ((const uint4 *)sdata)[j];
+                    uint32_t m = mask16_eq(c4, 0x3C3C3C3Cu);
+                    while (m) {
+                        const uint32_t b = __builtin_ctz(m);
+                        m &= m - 1;
+                        const uint32_t q = (uint32_t)(j * CHUNK) + b;
+                        if ((int)q >= s0_li) match_tag(sdata, H, cols, ht, q, evt, 0, RB);
                     }
                 }
-            } else {
-                // greedy left-to-right separator search (ccmdstr::splittocmd)
+            }
+            // ---- C/D. compact the tile's events into a dense list, then one lane per event
+            for (uint32_t w0 = 0; w0 < nev_tile; w0 += EVCAP) {
+                {
+                    uint64_t m = em;
+                    uint32_t idx = ev_base;
+                    while (m) {
+                        const int b = __builtin_ctzll(m);
+                        m &= m - 1;
+                        if (idx >= w0 && idx < w0 + EVCAP) {
+                            const uint32_t r = rank_base + (uint32_t)__builtin_popcountll(tm & ((1ull << b) - 1));
+                            evlist[idx - w0] = (uint32_t)(my_li + b) | (r << 16);
+                        }
+                        ++idx;
+                    }
+                }
+                __syncthreads();
+                const uint32_t cnt = nev_tile - w0 < EVCAP ? nev_tile - w0 : EVCAP;
+                for (uint32_t e = tid; e < cnt; e += BLOCK) {
+                    const uint32_t ev = evlist[e];
+                    const uint32_t q = ev & 0xFFFFu, r = ev >> 16;
+                    if (r >= rb0 && r < rb0 + RBn) match_tag(sdata, H, cols, ht, q, evt, r - rb0, RB);
+                }
+                __syncthreads();
+            }
+        }
+        STAMP(3);  // events
+
+        // ---- E. cells: descriptor, length, typed value
+        if (csv) {
+            // greedy left-to-right separator search, one lane per record (ccmdstr::splittocmd)
+            if ((uint32_t)tid < RBn) {
+                const uint32_t r = tid;
+                const uint32_t rs = recend[r] + 1, re = recend[r + 1];
+                uint32_t fmw = 0;
                 uint32_t pos = rs;
                 bool done = false;
-                const uint32_t s0b = cx.H->sep[0];
+                const uint32_t s0b = H->sep[0];
                 for (uint32_t c = 0; c < ncols; ++c) {
                     uint32_t fs = pos, fl = 0;
-                    bool have = !done;
-                    if (have) {
+                    if (!done) {
                         uint32_t p = pos;
                         bool hit = false;
                         while (p + seplen <= re) {
                             if (sdata[p] == s0b) {
                                 bool eq = true;
                                 for (uint32_t k = 1; k < seplen; ++k)
-                                    if (sdata[p + k] != cx.H->sep[k]) {
+                                    if (sdata[p + k] != H->sep[k]) {
                                         eq = false;
                                         break;
                                     }
@@ -455,7 +554,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                             fl = re - pos;
                             done = true;
                         }
-                        if (cx.H->bdelspace) {
+                        if (H->bdelspace) {
                             // deletelchr then deleterchr with its "pos != 0" test
                             // (public/_public.cpp:24-31, :52-59)
                             while (fl && sdata[fs] == ' ') {
@@ -468,40 +567,89 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                                 if (lastp != 0) fl = lastp + 1;
                             }
                         }
-                        const DevCol &col = cx.cols[c];
+                        const DevCol &col = cols[c];
                         if (col.collen > 0 && (uint32_t)col.collen < fl) fl = (uint32_t)col.collen;
                         fmw |= 1u << (c & 31);
                     }
-                    dstart[c * RB + r] = fs;
-                    dlen[c * RB + r] = fl;
+                    desc[c * RB + r] = desc_pack(fs, fl, LVL_CHAR);
                     if ((c & 31) == 31 || c + 1 == ncols) {
                         fmask[r * W + (c >> 5)] = fmw;
                         fmw = 0;
                     }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
+        STAMP(4);  // delimited descriptors
 
-        // ---- 4. one lane per cell: measure and convert
         const uint32_t items = RBn * ncols;
+        const bool nulcut = carry && !csv;
         for (uint32_t i = tid; i < items; i += BLOCK) {
             const uint32_t c = i / RBn, r = i - c * RBn;
             const uint32_t idx = c * RB + r;
-            const uint32_t s = dstart[idx], dl = dlen[idx];
-            const uint32_t len = dl & 0x3FFFFFFFu, lvl = dl >> 30;
-            const uint32_t typed = cx.cols[c].typed;
-            const bool nulcut = carry && !csv;
+            uint32_t s, len, lvl;
+            bool found;
+            if (csv) {
+                const uint32_t d = desc[idx];
+                s = d & 0x7FFFu;
+                len = (d >> 15) & 0x7FFFu;
+                lvl = LVL_CHAR;
+                found = (fmask[r * W + (c >> 5)] >> (c & 31)) & 1u;
+            } else {
+                // getxmlbuffer's independent first-open / first-close search, then splitbuffer's
+                // carry-forward: a missing tag keeps the nearest earlier column's value, filtered
+                // by every column in between
+                const uint32_t re = recend[r + 1];
+                uint32_t o = evt[(2 * c) * RB + r], e = evt[(2 * c + 1) * RB + r];
+                found = (o != NONE) & (e != NONE);
+                uint32_t cs = c;
+                lvl = cols[c].level;
+                bool have = found;
+                if (!found && carry) {
+                    while (cs > 0) {
+                        --cs;
+                        o = evt[(2 * cs) * RB + r];
+                        e = evt[(2 * cs + 1) * RB + r];
+                        if ((o != NONE) & (e != NONE)) {
+                            have = true;
+                            break;
+                        }
+                        if (cols[cs].level > lvl) lvl = cols[cs].level;
+                    }
+                }
+                if (have) {
+                    const DevCol &sc = cols[cs];
+                    s = o + sc.namelen + 2;
+                    int l = (int)e - (int)s;
+                    if (l < 0)
+                        l = (int)(re - s);  // close tag in front of the open tag: rest of record
+                    else if (sc.collen > 0 && sc.collen < l)
+                        l = sc.collen;
+                    len = (uint32_t)l;
+                    if (cs != c && sc.level > lvl) lvl = sc.level;
+                } else {
+                    s = 0;
+                    len = 0;
+                }
+                if (found) atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
+                desc[idx] = desc_pack(s, len, lvl);
+            }
+            const uint32_t typed = cols[c].typed;
+            const bool convert = typed != T_NONE && (found || nulcut);
             uint32_t flen;
-            const bool found = (fmask[r * W + (c >> 5)] >> (c & 31)) & 1u;
-            const bool convert = typed != T_NONE && (found || (carry && !csv));
             if (!convert && lvl == LVL_CHAR && !(nulcut && has_nul)) {
                 flen = len;
             } else {
                 uint64_t value = 0;
                 bool valid = false, range = false;
-                flen = cell_walk<false>(sdata + s, len, lvl, nulcut, convert ? typed : (uint32_t)T_NONE, nullptr,
-                                        value, valid, range);
+                const uint32_t ty = convert ? typed : (uint32_t)T_NONE;
+                if (len <= 16) {
+                    const uint4 w4 = lds_u128(sdata + s);
+                    flen = cell_walk16<false>((uint64_t)w4.x | ((uint64_t)w4.y << 32), (uint64_t)w4.z | ((uint64_t)w4.w << 32),
+                                              len, lvl, nulcut, ty, nullptr, value, valid, range);
+                } else {
+                    flen = cell_walk<false>(sdata + s, len, lvl, nulcut, ty, nullptr, value, valid, range);
+                }
                 if (convert) {
                     if (valid) atomicOr(&vmask[r * W + (c >> 5)], 1u << (c & 31));
                     if (range) atomicOr(P.status, ST_NUMERIC_RANGE);
@@ -512,15 +660,16 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             olen[idx] = flen;
         }
         __syncthreads();
+        STAMP(5);  // cells: measure + convert
 
-        // ---- 5. per-column exclusive prefix over the batch (one wave per column)
+        // ---- F. per-column exclusive prefix over the batch (one wave per column)
         for (uint32_t c = wave; c < ncols; c += BLOCK / 64) {
-            uint32_t v[4], sum = 0;
+            uint32_t x[4], sum = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t r = lane * 4 + k;
-                v[k] = r < RBn ? olen[c * RB + r] : 0;
-                sum += v[k];
+                x[k] = r < RBn ? olen[c * RB + r] : 0;
+                sum += x[k];
             }
             const uint32_t incl = wave_incl_scan(sum);
             uint32_t run = incl - sum;
@@ -528,11 +677,12 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             for (int k = 0; k < 4; ++k) {
                 const uint32_t r = lane * 4 + k;
                 if (r < RBn) olen[c * RB + r] = run;
-                run += v[k];
+                run += x[k];
             }
             if (lane == 63) coltot[c] = incl;
         }
         __syncthreads();
+        STAMP(6);  // column scans
 
         if (WRITE) {
             // where each column's bytes of this batch go; staging mirrors the 16-byte phase
@@ -550,9 +700,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                     }
                     sb = ((uint32_t)nxt + 15) & ~15u;
                 }
-                msa[MS_STAGED] = fits ? 1 : 0;
+                ms[MS_STAGED] = fits ? 1 : 0;
             }
             __syncthreads();
+            STAMP(7);  // stage bases
             const bool staged = ms[MS_STAGED] != 0;
             for (uint32_t i = tid; i < items; i += BLOCK) {
                 const uint32_t c = i / RBn, r = i - c * RBn;
@@ -562,15 +713,22 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 const uint64_t gb = tb[c] + tiletot[c];
                 P.off[c][row0 + rb0 + r + 1] = (uint32_t)(gb + end);
                 if (end > ex) {
-                    const uint32_t dl = dlen[idx];
+                    const uint32_t d = desc[idx];
+                    const uint32_t s = d & 0x7FFFu, len = (d >> 15) & 0x7FFFu, lvl = d >> 30;
                     uint8_t *dst = staged ? stage + stagebase[c] + ex : P.bytes[c] + gb + ex;
                     uint64_t dv;
                     bool b1, b2;
-                    cell_walk<true>(sdata + dstart[idx], dl & 0x3FFFFFFFu, dl >> 30, carry && !csv, T_NONE, dst, dv,
-                                    b1, b2);
+                    if (len <= 16) {
+                        const uint4 w4 = lds_u128(sdata + s);
+                        cell_walk16<true>((uint64_t)w4.x | ((uint64_t)w4.y << 32), (uint64_t)w4.z | ((uint64_t)w4.w << 32), len,
+                                          lvl, nulcut, T_NONE, dst, dv, b1, b2);
+                    } else {
+                        cell_walk<true>(sdata + s, len, lvl, nulcut, T_NONE, dst, dv, b1, b2);
+                    }
                 }
             }
             __syncthreads();
+            STAMP(8);  // cell copy into staging + offsets
             if (staged) {
                 for (uint32_t c = wave; c < ncols; c += BLOCK / 64) {
                     const uint32_t tot = coltot[c];
@@ -590,7 +748,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             }
             if ((uint32_t)tid < RBn) {
                 const uint64_t row = row0 + rb0 + tid;
-                if (P.rec_off) P.rec_off[row + 1] = (uint64_t)(cx.base_pos + (int64_t)recend[tid + 1] + 1);
+                if (P.rec_off) P.rec_off[row + 1] = (uint64_t)(base_pos + (int64_t)recend[tid + 1] + 1);
                 for (uint32_t w = 0; w < W; ++w) {
                     P.valid[row * W + w] = vmask[tid * W + w];
                     P.found[row * W + w] = fmask[tid * W + w];
@@ -598,6 +756,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             }
         }
         __syncthreads();
+        STAMP(9);  // copy-out + row outputs
         for (uint32_t c = tid; c < ncols; c += BLOCK) tiletot[c] += coltot[c];
         if (tid == 0) recend[0] = recend[RBn];
         __syncthreads();
