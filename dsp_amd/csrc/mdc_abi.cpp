@@ -151,7 +151,8 @@ struct mdc_parser {
     std::vector<int> typed;
     std::vector<uint8_t> blob;
     void *d_blob = nullptr;
-    LdsLayout L{};
+    LdsLayout Ls[3]{};  // one layout per look-behind level
+    int lb_level = 0;   // level that fitted the previous parse
     // workspace
     uint32_t *d_counts = nullptr;
     uint64_t *d_base = nullptr;
@@ -190,22 +191,20 @@ struct mdc_batch {
 
 static uint32_t round16(uint32_t v) { return (v + 15) & ~15u; }
 
-static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32_t blob_bytes, LdsLayout &L) {
-    uint32_t RB = 128;
+static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32_t blob_bytes, uint32_t lbmax,
+                           LdsLayout &L) {
+    uint32_t RB = 120;
     for (;;) {
         uint32_t o = 0;
+        L.lbmax = lbmax;
         L.data = o;
-        o += round16(TILE + LBMAX + DATA_SLACK);
+        o += round16(TILE + lbmax + DATA_SLACK);
         L.evlist = o;
-        L.evcap = 3072;
+        L.evcap = 1536;
         L.stage_cap = L.evcap * 4;
         o += L.evcap * 4;
         L.evt = o;
-        o += round16(RB * npat * 4);
-        L.desc = o;
-        o += round16(RB * ncols * 4);
-        L.olen = o;
-        o += round16(RB * ncols * 4 + 4);
+        o += round16(RB * (npat > ncols ? npat : ncols) * 4);
         L.recend = o;
         o += round16((RB + 1) * 4);
         L.vmask = o;
@@ -213,50 +212,39 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         L.fmask = o;
         o += round16(RB * words * 4);
         L.coltot = o;
-        o += round16(3 * (ncols + 1) * 4);
+        o += round16(2 * (ncols + 1) * 4);
         L.schema = o;
         o += round16(blob_bytes);
         L.misc = o;
-        o += 256;
+        o += 64;
         L.total = o;
         L.RB = RB;
-        if (o <= 80 * 1024 || RB <= 8) break;
-        RB /= 2;
+        if (o <= 40 * 1024 || RB <= 8) break;
+        if (RB > 64 && lbmax > 2048) break;  // the larger look-behind configurations trade occupancy
+        RB = RB > 16 ? RB - 8 : RB / 2;
     }
 }
+
+// look-behind capacities tried in turn when a record does not fit (fewer blocks per CU each)
+static const uint32_t LB_LEVELS[3] = {2048, 8192, LBMAX};
 
 static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *sep, int bdelspace) {
     const uint32_t ncols = (uint32_t)p->ncols;
     const uint32_t npat = p->mode == MODE_XML ? 2 * ncols : 0;
-    uint32_t ht_size = 16;
-    while (ht_size < 4 * npat) ht_size <<= 1;
-    const size_t cols_bytes = (ncols * sizeof(DevCol) + 15) & ~(size_t)15;
-    p->blob.assign(sizeof(SchemaHdr) + cols_bytes + ht_size * sizeof(HtEntry), 0);
-    SchemaHdr *H = (SchemaHdr *)p->blob.data();
-    DevCol *dc = (DevCol *)(H + 1);
-    HtEntry *ht = (HtEntry *)((uint8_t *)dc + cols_bytes);
-    H->ncols = ncols;
-    H->npat = npat;
-    H->ht_mask = ht_size - 1;
-    H->carry = carry ? 1 : 0;
-    H->mode = p->mode;
-    H->words = p->words;
-    H->bdelspace = bdelspace ? 1 : 0;
     size_t el = strlen(endbz);
     if (el > MAX_ENDBZ) return fail(MDC_ERR_ARG, "endbz longer than %d bytes", MAX_ENDBZ);
     if (memchr(endbz, '\n', el)) return fail(MDC_ERR_ARG, "endbz must not contain a newline");
-    H->endbz_len = (uint32_t)el;
-    memcpy(H->endbz, endbz, el);
-    if (el <= 8) memcpy(H->endbz_tail + 8 - el, endbz, el);
+    size_t sl = 0;
     if (p->mode == MODE_CSV) {
-        size_t sl = strlen(sep);
+        sl = strlen(sep);
         if (sl == 0 || sl > MAX_SEP) return fail(MDC_ERR_ARG, "separator must be 1..%d bytes", MAX_SEP);
         if (memchr(sep, '\n', sl)) return fail(MDC_ERR_ARG, "separator must not contain a newline");
-        H->sep_len = (uint32_t)sl;
-        memcpy(H->sep, sep, sl);
     }
+    std::vector<DevCol> dc(ncols);
+    uint32_t any_typed = 0;
     for (uint32_t c = 0; c < ncols; ++c) {
         const mdc_col &col = p->cols[c];
+        memset(&dc[c], 0, sizeof(DevCol));
         size_t nl = strnlen(col.colname, 32);
         if (nl > 31) return fail(MDC_ERR_ARG, "column %u: name not NUL-terminated", c);
         if (memchr(col.colname, '>', nl) || memchr(col.colname, '\n', nl))
@@ -274,30 +262,123 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
         if (t < MDC_T_NONE || t > MDC_T_BOOL) return fail(MDC_ERR_ARG, "column %u: bad typed code %d", c, t);
         p->typed[c] = t;
         dc[c].typed = (uint8_t)t;
-        if (t != MDC_T_NONE) H->any_typed = 1;
+        if (t != MDC_T_NONE) any_typed = 1;
         dc[c].collen = col.collen;
-        if (p->mode != MODE_XML) continue;
+    }
+
+    // tag texts -> perfect hash
+    struct Pat {
+        uint8_t text[48];  // text + '>' padded with zeros
+        uint32_t tlen, col, kind, lo, hi;
+    };
+    std::vector<Pat> pats;
+    for (uint32_t c = 0; c < ncols && p->mode == MODE_XML; ++c)
         for (uint32_t kind = 0; kind < 2; ++kind) {
-            uint8_t text[40];
+            Pat q;
+            memset(&q, 0, sizeof q);
             uint32_t tlen = 0;
-            if (kind) text[tlen++] = '/';
-            memcpy(text + tlen, col.colname, nl);
-            tlen += (uint32_t)nl;
-            text[tlen] = '>';
+            if (kind) q.text[tlen++] = '/';
+            memcpy(q.text + tlen, dc[c].name, dc[c].namelen);
+            tlen += dc[c].namelen;
+            q.text[tlen] = '>';
+            q.tlen = tlen;
+            q.col = c;
+            q.kind = kind;
             uint8_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            memcpy(key, text, tlen + 1 < 8 ? tlen + 1 : 8);
-            uint32_t lo, hi;
-            memcpy(&lo, key, 4);
-            memcpy(&hi, key + 4, 4);
-            uint32_t slot = ht_hash(lo, hi) & H->ht_mask;
-            while (ht[slot].meta >> 31) slot = (slot + 1) & H->ht_mask;
-            ht[slot].klo = lo;
-            ht[slot].khi = hi;
-            ht[slot].meta = 0x80000000u | (c << 16) | (kind << 8) | tlen;
+            memcpy(key, q.text, tlen + 1 < 8 ? tlen + 1 : 8);
+            memcpy(&q.lo, key, 4);
+            memcpy(&q.hi, key + 4, 4);
+            pats.push_back(q);
+        }
+    uint32_t ht_size = 16, seed = 0;
+    while (ht_size < 2 * npat) ht_size <<= 1;
+    std::vector<int> head;  // slot -> first pattern index with that key, or -1
+    for (;;) {
+        bool ok = false;
+        for (seed = 0; seed < 4096 && !ok; ++seed) {
+            head.assign(ht_size, -1);
+            ok = true;
+            for (size_t i = 0; i < pats.size() && ok; ++i) {
+                uint32_t slot = ht_hash(pats[i].lo, pats[i].hi, seed * 0x9E3779B9u) & (ht_size - 1);
+                if (head[slot] < 0)
+                    head[slot] = (int)i;
+                else if (pats[head[slot]].lo != pats[i].lo || pats[head[slot]].hi != pats[i].hi)
+                    ok = false;  // two different keys in one slot
+            }
+        }
+        if (ok) {
+            --seed;
+            break;
+        }
+        ht_size <<= 1;
+        if (ht_size > 4096) return fail(MDC_ERR_INTERNAL, "could not build the tag hash table");
+    }
+    seed *= 0x9E3779B9u;
+    // chained entries (same key) go behind the hashed slots
+    std::vector<HtEntry> ht(ht_size);
+    memset(ht.data(), 0, ht.size() * sizeof(HtEntry));
+    auto fill = [&](HtEntry &e, const Pat &q) {
+        e.klo = q.lo;
+        e.khi = q.hi;
+        e.meta = 0x80000000u | (q.col << 16) | (q.kind << 8) | q.tlen;
+        if (q.tlen + 1 > 16) e.meta |= 0x40000000u;
+        uint8_t k2[8] = {0}, m2[8] = {0};
+        for (uint32_t k = 8; k < 16 && k <= q.tlen; ++k) {
+            k2[k - 8] = q.text[k];
+            m2[k - 8] = 0xFF;
+        }
+        memcpy(&e.k2lo, k2, 4);
+        memcpy(&e.k2hi, k2 + 4, 4);
+        memcpy(&e.m2lo, m2, 4);
+        memcpy(&e.m2hi, m2 + 4, 4);
+        e.next = 0;
+    };
+    for (size_t i = 0; i < pats.size(); ++i) {
+        uint32_t slot = ht_hash(pats[i].lo, pats[i].hi, seed) & (ht_size - 1);
+        if (head[slot] == (int)i) {
+            fill(ht[slot], pats[i]);
+        } else {
+            HtEntry e;
+            fill(e, pats[i]);
+            uint32_t at = slot;
+            while (ht[at].next) at = ht[at].next;
+            ht.push_back(e);
+            ht[at].next = (uint32_t)ht.size() - 1;
         }
     }
-    compute_layout(ncols, npat, p->words, (uint32_t)p->blob.size(), p->L);
-    if (p->L.total > 160 * 1024) return fail(MDC_ERR_ARG, "schema too large for LDS (%u bytes)", p->L.total);
+
+    const size_t cols_bytes = (ncols * sizeof(DevCol) + 15) & ~(size_t)15;
+    const size_t p10_off = sizeof(SchemaHdr) + cols_bytes + ht.size() * sizeof(HtEntry);
+    p->blob.assign(p10_off + 23 * sizeof(double) + 8, 0);
+    p->blob.resize((p->blob.size() + 15) & ~(size_t)15);
+    SchemaHdr *H = (SchemaHdr *)p->blob.data();
+    H->ncols = ncols;
+    H->npat = npat;
+    H->ht_mask = ht_size - 1;
+    H->ht_seed = seed;
+    H->p10_off = (uint32_t)p10_off;
+    H->carry = carry ? 1 : 0;
+    H->mode = p->mode;
+    H->words = p->words;
+    H->bdelspace = bdelspace ? 1 : 0;
+    H->any_typed = any_typed;
+    H->endbz_len = (uint32_t)el;
+    memcpy(H->endbz, endbz, el);
+    if (el <= 8) memcpy(H->endbz_tail + 8 - el, endbz, el);
+    H->sep_len = (uint32_t)sl;
+    if (sl) memcpy(H->sep, sep, sl);
+    memcpy(p->blob.data() + sizeof(SchemaHdr), dc.data(), ncols * sizeof(DevCol));
+    memcpy(p->blob.data() + sizeof(SchemaHdr) + cols_bytes, ht.data(), ht.size() * sizeof(HtEntry));
+    double p10 = 1.0;
+    for (int k = 0; k < 23; ++k) {
+        memcpy(p->blob.data() + p10_off + 8 * k, &p10, 8);
+        p10 *= 10.0;  // exact up to 1e22
+    }
+    for (int lv = 0; lv < 3; ++lv) {
+        compute_layout(ncols, npat, p->words, (uint32_t)p->blob.size(), LB_LEVELS[lv], p->Ls[lv]);
+        if (p->Ls[lv].total > 160 * 1024)
+            return fail(MDC_ERR_ARG, "schema too large for LDS (%u bytes)", p->Ls[lv].total);
+    }
     return MDC_OK;
 }
 
@@ -431,7 +512,8 @@ static int ensure_workspace(mdc_parser *p, size_t ntiles) {
 
 static int status_to_error(uint32_t st) {
     if (st & ST_RECORD_TOO_LONG)
-        return fail(MDC_ERR_RECORD_TOO_LONG, "a record is longer than the %d-byte look-behind window", LBMAX);
+        return fail(MDC_ERR_RECORD_TOO_LONG, "a record starts more than %d bytes in front of the tile that ends it",
+                    LBMAX);
     if (st) return fail(MDC_ERR_INTERNAL, "kernel status %#x", st);
     return MDC_OK;
 }
@@ -455,21 +537,31 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     P.schema = (const uint8_t *)p->d_blob;
     P.schema_bytes = (uint32_t)p->blob.size();
     P.ntiles = (uint32_t)ntiles;
-    P.L = p->L;
     P.tile_counts = p->d_counts;
     P.tile_base = p->d_base;
     P.status = p->d_status;
 
     hipStream_t s = d->stream;
-    HIP_TRY(hipMemsetAsync(p->d_status, 0, 4, s));
-    HIP_TRY(hipEventRecord(p->ev[0], s));
-    HIP_TRY(launch_tile_kernel(false, P, s));
-    HIP_TRY(hipEventRecord(p->ev[1], s));
-    HIP_TRY(launch_scan_tiles(p->d_counts, p->d_base, (uint32_t)ntiles, ncnt, s));
-    HIP_TRY(hipEventRecord(p->ev[2], s));
-    HIP_TRY(hipMemcpyAsync(p->h_totals, p->d_base + ntiles * ncnt, ncnt * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(p->h_totals + ncnt, p->d_status, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // Sizing pass.  The look-behind capacity starts at the level that fitted the previous
+    // parse; a record that does not fit raises ST_RECORD_TOO_LONG and the pass is repeated
+    // with the next larger capacity (which costs blocks per CU, so it is not the default).
+    for (;;) {
+        P.L = p->Ls[p->lb_level];
+        HIP_TRY(hipMemsetAsync(p->d_status, 0, 4, s));
+        HIP_TRY(hipEventRecord(p->ev[0], s));
+        HIP_TRY(launch_tile_kernel(false, P, s));
+        HIP_TRY(hipEventRecord(p->ev[1], s));
+        HIP_TRY(launch_scan_tiles(p->d_counts, p->d_base, (uint32_t)ntiles, ncnt, s));
+        HIP_TRY(hipEventRecord(p->ev[2], s));
+        HIP_TRY(hipMemcpyAsync(p->h_totals, p->d_base + ntiles * ncnt, ncnt * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(p->h_totals + ncnt, p->d_status, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (((uint32_t)p->h_totals[ncnt] & ST_RECORD_TOO_LONG) && p->lb_level < 2) {
+            ++p->lb_level;
+            continue;
+        }
+        break;
+    }
     rc = status_to_error((uint32_t)p->h_totals[ncnt] & ~ST_NUMERIC_RANGE);
     if (rc) return rc;
     mdc_timing &t = p->timing;

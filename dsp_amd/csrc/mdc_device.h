@@ -8,11 +8,11 @@ namespace mdc {
 // ---- tile geometry ---------------------------------------------------------------------
 // A tile is TILE consecutive input bytes.  A tile owns every record whose terminating '\n'
 // lies inside it; the first owned record may start up to LBMAX bytes in front of the tile
-// (look-behind).  The block keeps [tile_start-LBMAX, tile_start+TILE) in LDS, byte `pos` at
-// LDS index pos - tile_start + LBMAX.
+// (look-behind; the capacity is chosen per launch, LdsLayout::lbmax <= LBMAX).  The block keeps
+// [tile_start-lbmax, tile_start+TILE) in LDS, byte `pos` at LDS index pos - tile_start + lbmax.
 constexpr int BLOCK = 256;
 constexpr int TILE = 16384;
-constexpr int LBMAX = 8192;
+constexpr int LBMAX = 16320;                             // largest look-behind capacity
 constexpr int CHUNK = 16;                                // bytes per lane per step (one dwordx4)
 constexpr int DATA_SLACK = 64;                           // readable bytes past the image
 constexpr int LB_FIRST = 512;                            // first look-behind window
@@ -54,27 +54,33 @@ static_assert(sizeof(DevCol) == 40, "DevCol layout");
 #endif
 
 // hash of a tag key (the first eight bytes of text+'>' as two little-endian words)
-MDC_HD inline uint32_t ht_hash(uint32_t lo, uint32_t hi) {
-    uint32_t h = lo * 0x9E3779B1u + hi * 0x85EBCA77u;
+MDC_HD inline uint32_t ht_hash(uint32_t lo, uint32_t hi, uint32_t seed) {
+    uint32_t h = (lo ^ seed) * 0x9E3779B1u + hi * 0x85EBCA77u;
     return h ^ (h >> 15);
 }
 
-// open-addressed table of tag texts.  key = first min(8, tlen+1) bytes of text+'>'.
+// Perfect-hash table of tag texts: the host picks a seed under which all distinct keys fall
+// into distinct slots, so a lookup is ONE probe.  key = first min(8, tlen+1) bytes of
+// text+'>'; bytes 8..15 of text+'>' are compared through (k2 & m2); entries whose key is
+// shared (duplicate column names, names equal in their first eight bytes) are chained through
+// `next` (index into the same array, 0 = end; chain entries live behind the hashed slots).
 struct HtEntry {
     uint32_t klo, khi;
-    uint32_t meta;  // bit31 used | col<<16 | kind<<8 | tlen
-    uint32_t pad;
+    uint32_t meta;  // bit31 used | bit30 text longer than 16 bytes | col<<16 | kind<<8 | tlen
+    uint32_t next;
+    uint32_t k2lo, k2hi, m2lo, m2hi;
 };
+static_assert(sizeof(HtEntry) == 32, "HtEntry layout");
 
 struct SchemaHdr {
     uint32_t ncols, npat, ht_mask, endbz_len;
     uint32_t carry, mode, words, sep_len;
-    uint32_t bdelspace, any_typed, r1, r2;
+    uint32_t bdelspace, any_typed, ht_seed, p10_off;  // p10_off: byte offset of double[23] = 10^k
     uint8_t endbz[MAX_ENDBZ];
     uint8_t sep[MAX_SEP];
     uint8_t endbz_tail[8];  // endbz right-aligned in 8 bytes (when endbz_len <= 8)
     uint8_t pad8[8];
-    // followed by DevCol[ncols], then HtEntry[ht_mask+1] (16-byte aligned)
+    // followed by DevCol[ncols], HtEntry[ht_mask+1+chained] (16-byte aligned), double[23]
 };
 static_assert(sizeof(SchemaHdr) % 16 == 0, "SchemaHdr must keep 16-byte alignment");
 
@@ -82,19 +88,19 @@ static_assert(sizeof(SchemaHdr) % 16 == 0, "SchemaHdr must keep 16-byte alignmen
 struct LdsLayout {
     uint32_t data;    // TILE+LBMAX+DATA_SLACK bytes
     uint32_t evlist;  // evcap u32: dense list of '<' events (position | rank<<16); later the cell staging area
-    uint32_t evt;     // RB*npat u32: first position of every tag pattern per record
-    uint32_t desc;    // RB*ncols u32: cell descriptors
-    uint32_t olen;    // RB*ncols u32: cell lengths, then exclusive offsets
+    uint32_t evt;     // RB*max(npat,ncols) u32: first position of every tag pattern per record
+                      // (delimited mode: the field descriptors)
     uint32_t recend;  // (RB+1) u32
     uint32_t vmask;   // RB*words u32
     uint32_t fmask;   // RB*words u32
-    uint32_t coltot;  // 3*(ncols+1) u32: batch totals, tile totals, stage bases
+    uint32_t coltot;  // 2*(ncols+1) u32: batch totals, tile totals
     uint32_t schema;  // schema blob
     uint32_t misc;    // block-wide scalars
     uint32_t total;
     uint32_t RB;         // records per batch (<= 256)
     uint32_t evcap;      // events per compaction window
     uint32_t stage_cap;  // = evcap*4
+    uint32_t lbmax;      // look-behind capacity in bytes (multiple of 16)
 };
 
 struct TileParams {

@@ -183,8 +183,9 @@ __device__ __forceinline__ bool is_term(const uint8_t *sdata, const SchemaHdr *H
     return true;
 }
 
-// Tag lookup for the '<' at LDS index q: one unaligned 8-byte read gives the key, the hash
-// table is probed until an empty slot; each hit lowers first_pos[pattern][record].
+// Tag lookup for the '<' at LDS index q: one unaligned 8-byte read gives the key, ONE probe of
+// the perfect-hash table finds the entry (or none); a hit lowers first_pos[pattern][record].
+// Entries that share a key are chained and told apart by the rest of their text.
 __device__ __forceinline__ void match_tag(const uint8_t *sdata, const SchemaHdr *H, const DevCol *cols,
                                           const HtEntry *ht, uint32_t q, uint32_t *evt, uint32_t rl, uint32_t RB) {
     const uint32_t a = q + 1;
@@ -199,82 +200,148 @@ __device__ __forceinline__ void match_tag(const uint8_t *sdata, const SchemaHdr 
         const uint32_t g = (uint32_t)__builtin_ctz(ghi) >> 3;
         hi &= 0xFFFFFFFFu >> (8 * (3 - g));
     }
-    uint32_t slot = ht_hash(lo, hi) & H->ht_mask;
+    uint32_t slot = ht_hash(lo, hi, H->ht_seed) & H->ht_mask;
+    const uint4 e0 = *(const uint4 *)&ht[slot];
+    if (!(e0.z >> 31) || e0.x != lo || e0.y != hi) return;
     for (;;) {
-        const HtEntry e = ht[slot];
-        if (!(e.meta >> 31)) break;
-        if (e.klo == lo && e.khi == hi) {
-            const uint32_t tlen = e.meta & 0xFFu, kind = (e.meta >> 8) & 1u, col = (e.meta >> 16) & 0x7FFFu;
-            bool ok = true;
-            if (tlen >= 8) {  // texts of 8+ bytes share their key with longer ones: compare the tail
+        const HtEntry &e = ht[slot];
+        const uint32_t meta = e.meta;
+        const uint32_t tlen = meta & 0xFFu, kind = (meta >> 8) & 1u, col = (meta >> 16) & 0x3FFFu;
+        bool ok = true;
+        if (tlen >= 8) {  // the key covers eight bytes; compare the rest of text+'>'
+            const uint64_t w2 = lds_u64(sdata + a + 8);
+            ok = (((uint32_t)w2 ^ e.k2lo) & e.m2lo) == 0 && (((uint32_t)(w2 >> 32) ^ e.k2hi) & e.m2hi) == 0;
+            if (ok && (meta & 0x40000000u)) {
                 const uint8_t *nm = cols[col].name;
-                for (uint32_t k = 8; k < tlen; ++k)
+                for (uint32_t k = 16; k < tlen; ++k)
                     if (sdata[a + k] != nm[k - kind]) {
                         ok = false;
                         break;
                     }
                 if (ok && sdata[a + tlen] != '>') ok = false;
             }
-            if (ok) atomicMin(&evt[(2 * col + kind) * RB + rl], q);
         }
-        slot = (slot + 1) & H->ht_mask;
+        if (ok) atomicMin(&evt[(2 * col + kind) * RB + rl], q);
+        slot = e.next;
+        if (!slot) break;
     }
 }
 
-// Register-resident variant of cell_walk for cells of at most 16 source bytes (lo = bytes
-// 0..7, hi = bytes 8..15 of the source).
+// Cells of at most 16 source bytes, held in registers (lo = bytes 0..7, hi = bytes 8..15).
+// One predicated pass per byte does picknumber's filter, the NUL cut, the cell length and the
+// whole [+-]digits[.digits] prefix grammar of std::sto* (mdc_numparse.h) without a branch:
+// a 16-byte text has at most 16 digits, so the digits fit one u64 and nothing can overflow.
+// EMIT=true writes the surviving bytes to dst instead.
 template <bool EMIT>
-__device__ __forceinline__ uint32_t cell_walk16(uint64_t lo, uint64_t hi, uint32_t len, uint32_t lvl, bool nulcut,
-                                               uint32_t typed, uint8_t *dst, uint64_t &value, bool &valid,
-                                               bool &range) {
+__device__ __forceinline__ uint32_t cell_scan16(uint64_t lo, uint64_t hi, uint32_t len, uint32_t lvl, bool nulcut,
+                                               uint32_t typed, const double *p10, uint8_t *dst, uint64_t &value,
+                                               bool &valid) {
     uint32_t out = 0;
-    NumAcc acc;
-    bool boolok = true;
-    const bool isfloat = (typed == T_F64 || typed == T_F32);
-    const bool issigned = (typed == T_I32 || typed == T_I64 || isfloat);
-    if (!EMIT) num_init(acc);
+    const bool isfloat = (typed == T_F64) | (typed == T_F32);
+    const bool issigned = (typed == T_I32) | (typed == T_I64) | isfloat;
+    const bool cut = nulcut & (lvl == LVL_CHAR);
+    uint64_t m = 0;
+    uint32_t k10 = 0;
+    bool seenq = false, stop = false, neg = false, seendot = false, any = false, boolok = true, dead = false;
     for (uint32_t k = 0; k < len; ++k) {
         const uint32_t b = (uint32_t)lo & 0xFFu;
         lo = (lo >> 8) | (hi << 56);
         hi >>= 8;
-        const bool dig = (b - '0') < 10u;
+        const uint32_t d = b - '0';
+        const bool dig = d < 10u;
         const bool sgn = (b == '+') | (b == '-');
         const bool dot = (b == '.');
-        bool pass;
-        if (lvl == LVL_CHAR) {
-            if (nulcut && b == 0) break;
-            pass = true;
-        } else if (lvl == LVL_NUMBER) {
-            pass = dig | sgn | dot;
-        } else {
-            pass = dig;
-        }
-        if (!pass) continue;
+        dead |= cut & (b == 0);
+        const bool pass = !dead & (lvl == LVL_CHAR ? true : lvl == LVL_NUMBER ? (dig | sgn | dot) : dig);
         if (EMIT) {
-            dst[out] = (uint8_t)b;
-        } else if (typed != T_NONE) {
+            if (pass) dst[out] = (uint8_t)b;
+        } else {
             if (typed == T_BOOL) {
                 const uint32_t u = (b >= 'a' && b <= 'z') ? b - 32 : b;
                 const uint32_t want = out == 0 ? 'T' : out == 1 ? 'R' : out == 2 ? 'U' : out == 3 ? 'E' : 0x100;
-                boolok = boolok && (u == want);
-            } else if (dig | (issigned & sgn) | (isfloat & dot)) {
-                num_feed(acc, b, isfloat);
+                boolok &= !pass | (u == want);
+            } else {
+                const bool q = pass & (dig | (issigned & sgn) | (isfloat & dot));
+                const bool first = q & !seenq;
+                stop |= (q & sgn & !first) | (q & dot & seendot);
+                const bool live = q & !stop;
+                neg |= live & first & (b == '-');
+                const bool ld = live & dig;
+                m = ld ? m * 10 + d : m;
+                k10 += (ld & seendot) ? 1 : 0;
+                any |= ld;
+                seendot |= live & dot;
+                seenq |= q;
             }
         }
-        ++out;
+        out += pass ? 1 : 0;
     }
-    if (!EMIT && typed != T_NONE) {
-        if (typed == T_BOOL) {
+    if (EMIT || typed == T_NONE) return out;
+    valid = false;
+    value = 0;
+    if (typed == T_BOOL) {
+        valid = true;
+        value = (boolok && out == 4) ? 1 : 0;
+        return out;
+    }
+    if (!any) return out;
+    switch (typed) {
+    case T_I32:
+        if (m <= (neg ? 0x80000000ull : 0x7fffffffull)) {
             valid = true;
-            value = (boolok && out == 4) ? 1 : 0;
-        } else {
-            uint64_t v = 0;
-            valid = num_finish(acc, typed, v, range);
-            value = valid ? v : 0;
+            value = neg ? (uint64_t)(-(int64_t)m) : m;
         }
+        break;
+    case T_U32:
+        if (m <= 0x7fffffffull) {
+            valid = true;
+            value = m;
+        }
+        break;
+    case T_I64:
+    case T_U64:  // at most 16 digits: always in range
+        valid = true;
+        value = neg ? (uint64_t)0 - m : m;
+        break;
+    case T_F64:
+        valid = true;
+        if (m == 0) {
+            value = neg ? 1ull << 63 : 0;
+        } else if (m < (1ull << 53)) {
+            double x = (double)m / p10[k10];  // both exact (k10 <= 16): one correctly rounded division
+            value = (uint64_t)__double_as_longlong(neg ? -x : x);
+        } else {
+            int e;
+            uint64_t mant;
+            u128 M;
+            M.hi = 0;
+            M.lo = m;
+            div_round(M, k10, 53, e, mant);
+            value = ((uint64_t)neg << 63) | ((uint64_t)(e + 1023) << 52) | (mant & ((1ull << 52) - 1));
+        }
+        break;
+    default: {  // T_F32: one rounding, directly from the decimal
+        if (m == 0) {
+            valid = true;
+            value = neg ? 1ull << 31 : 0;
+            break;
+        }
+        int e;
+        uint64_t mant;
+        u128 M;
+        M.hi = 0;
+        M.lo = m;
+        div_round(M, k10, 24, e, mant);
+        if (e + 127 > 0 && e + 127 < 255) {
+            valid = true;
+            value = ((uint64_t)neg << 31) | ((uint64_t)(e + 127) << 23) | (mant & ((1ull << 23) - 1));
+        }
+    }
     }
     return out;
 }
+
+constexpr int RB_PASSES = 2;  // records per batch <= 64 * RB_PASSES
 
 // descriptor of one cell: source start (15 bits) | source length (15 bits) | filter level (2)
 __device__ __forceinline__ uint32_t desc_pack(uint32_t start, uint32_t len, uint32_t lvl) {
@@ -288,8 +355,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     uint8_t *sdata = smem + L.data;
     uint32_t *evlist = (uint32_t *)(smem + L.evlist);
     uint32_t *evt = (uint32_t *)(smem + L.evt);
-    uint32_t *olen = (uint32_t *)(smem + L.olen);
-    uint32_t *desc = (uint32_t *)(smem + L.desc);
+    uint32_t *desc = (uint32_t *)(smem + L.evt);  // delimited mode has no tag events: same space
     uint32_t *recend = (uint32_t *)(smem + L.recend);
     uint32_t *vmask = (uint32_t *)(smem + L.vmask);
     uint32_t *fmask = (uint32_t *)(smem + L.fmask);
@@ -303,9 +369,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     const int64_t n = (int64_t)P.n;
     const int64_t tile_start = (int64_t)blockIdx.x * TILE;
     const int64_t tile_end = (tile_start + TILE < n) ? tile_start + TILE : n;
-    const int64_t base_pos = tile_start - LBMAX;  // global position of LDS index 0
-    const int ts_li = LBMAX;
-    const int te_li = LBMAX + (int)(tile_end - tile_start);
+    const int LB = (int)L.lbmax;                // look-behind capacity of this launch
+    const int64_t base_pos = tile_start - LB;  // global position of LDS index 0
+    const int ts_li = LB;
+    const int te_li = LB + (int)(tile_end - tile_start);
     const int li_min = base_pos < 0 ? (int)(-base_pos) : 0;
 
     auto load_chunk = [&](int j) -> uint4 {  // 16-byte chunk j of the LDS image, from global memory
@@ -347,7 +414,6 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     const bool carry = H->carry != 0;
     uint32_t *coltot = (uint32_t *)(smem + L.coltot);  // totals of the current batch
     uint32_t *tiletot = coltot + (ncols + 1);          // totals of the batches done so far
-    uint32_t *stagebase = tiletot + (ncols + 1);
     for (uint32_t c = tid; c < ncols + 1; c += BLOCK) tiletot[c] = 0;
 
     // look behind for the start of the first owned record
@@ -582,182 +648,151 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         }
         STAMP(4);  // delimited descriptors
 
-        const uint32_t items = RBn * ncols;
         const bool nulcut = carry && !csv;
-        for (uint32_t i = tid; i < items; i += BLOCK) {
-            const uint32_t c = i / RBn, r = i - c * RBn;
-            const uint32_t idx = c * RB + r;
-            uint32_t s, len, lvl;
-            bool found;
-            if (csv) {
-                const uint32_t d = desc[idx];
-                s = d & 0x7FFFu;
-                len = (d >> 15) & 0x7FFFu;
-                lvl = LVL_CHAR;
-                found = (fmask[r * W + (c >> 5)] >> (c & 31)) & 1u;
-            } else {
-                // getxmlbuffer's independent first-open / first-close search, then splitbuffer's
-                // carry-forward: a missing tag keeps the nearest earlier column's value, filtered
-                // by every column in between
-                const uint32_t re = recend[r + 1];
-                uint32_t o = evt[(2 * c) * RB + r], e = evt[(2 * c + 1) * RB + r];
-                found = (o != NONE) & (e != NONE);
-                uint32_t cs = c;
-                lvl = cols[c].level;
-                bool have = found;
-                if (!found && carry) {
-                    while (cs > 0) {
-                        --cs;
-                        o = evt[(2 * cs) * RB + r];
-                        e = evt[(2 * cs + 1) * RB + r];
-                        if ((o != NONE) & (e != NONE)) {
-                            have = true;
-                            break;
-                        }
-                        if (cols[cs].level > lvl) lvl = cols[cs].level;
-                    }
-                }
-                if (have) {
-                    const DevCol &sc = cols[cs];
-                    s = o + sc.namelen + 2;
-                    int l = (int)e - (int)s;
-                    if (l < 0)
-                        l = (int)(re - s);  // close tag in front of the open tag: rest of record
-                    else if (sc.collen > 0 && sc.collen < l)
-                        l = sc.collen;
-                    len = (uint32_t)l;
-                    if (cs != c && sc.level > lvl) lvl = sc.level;
-                } else {
-                    s = 0;
-                    len = 0;
-                }
-                if (found) atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
-                desc[idx] = desc_pack(s, len, lvl);
-            }
-            const uint32_t typed = cols[c].typed;
-            const bool convert = typed != T_NONE && (found || nulcut);
-            uint32_t flen;
-            if (!convert && lvl == LVL_CHAR && !(nulcut && has_nul)) {
-                flen = len;
-            } else {
-                uint64_t value = 0;
-                bool valid = false, range = false;
-                const uint32_t ty = convert ? typed : (uint32_t)T_NONE;
-                if (len <= 16) {
-                    const uint4 w4 = lds_u128(sdata + s);
-                    flen = cell_walk16<false>((uint64_t)w4.x | ((uint64_t)w4.y << 32), (uint64_t)w4.z | ((uint64_t)w4.w << 32),
-                                              len, lvl, nulcut, ty, nullptr, value, valid, range);
-                } else {
-                    flen = cell_walk<false>(sdata + s, len, lvl, nulcut, ty, nullptr, value, valid, range);
-                }
-                if (convert) {
-                    if (valid) atomicOr(&vmask[r * W + (c >> 5)], 1u << (c & 31));
-                    if (range) atomicOr(P.status, ST_NUMERIC_RANGE);
-                    if (WRITE && P.val[c]) P.val[c][row0 + rb0 + r] = value;
-                }
-            }
-            if (!convert && WRITE && typed != T_NONE && P.val[c]) P.val[c][row0 + rb0 + r] = 0;
-            olen[idx] = flen;
-        }
-        __syncthreads();
-        STAMP(5);  // cells: measure + convert
-
-        // ---- F. per-column exclusive prefix over the batch (one wave per column)
+        const double *p10 = (const double *)(smem + L.schema + H->p10_off);
+        // ---- E-H. one wave per column, one lane per record; everything about a column (cell
+        // descriptors, lengths, typed values, offsets, staging, copy-out) stays inside the wave,
+        // so no block barrier is needed until the row outputs
+        uint8_t *const wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
+        const uint32_t wstage_cap = L.stage_cap / (BLOCK / 64);
         for (uint32_t c = wave; c < ncols; c += BLOCK / 64) {
-            uint32_t x[4], sum = 0;
+            const uint32_t typed = cols[c].typed;
+            const uint32_t clvl = cols[c].level;
+            uint64_t *const valp = (WRITE && typed != T_NONE) ? P.val[c] : nullptr;
+            uint32_t cs_[RB_PASSES], cl_[RB_PASSES], cv_[RB_PASSES], cf_[RB_PASSES], cx_[RB_PASSES];
+            uint32_t total = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t r = lane * 4 + k;
-                x[k] = r < RBn ? olen[c * RB + r] : 0;
-                sum += x[k];
-            }
-            const uint32_t incl = wave_incl_scan(sum);
-            uint32_t run = incl - sum;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t r = lane * 4 + k;
-                if (r < RBn) olen[c * RB + r] = run;
-                run += x[k];
-            }
-            if (lane == 63) coltot[c] = incl;
-        }
-        __syncthreads();
-        STAMP(6);  // column scans
-
-        if (WRITE) {
-            // where each column's bytes of this batch go; staging mirrors the 16-byte phase
-            if (tid == 0) {
-                uint32_t sb = 0;
-                bool fits = true;
-                for (uint32_t c = 0; c < ncols; ++c) {
-                    const uint64_t gb = tb[c] + tiletot[c];
-                    const uint32_t a = (uint32_t)(gb & 15);
-                    stagebase[c] = sb + a;
-                    const uint64_t nxt = (uint64_t)sb + a + coltot[c];
-                    if (nxt > L.stage_cap) {
-                        fits = false;
-                        break;
-                    }
-                    sb = ((uint32_t)nxt + 15) & ~15u;
-                }
-                ms[MS_STAGED] = fits ? 1 : 0;
-            }
-            __syncthreads();
-            STAMP(7);  // stage bases
-            const bool staged = ms[MS_STAGED] != 0;
-            for (uint32_t i = tid; i < items; i += BLOCK) {
-                const uint32_t c = i / RBn, r = i - c * RBn;
-                const uint32_t idx = c * RB + r;
-                const uint32_t ex = olen[idx];
-                const uint32_t end = (r + 1 < RBn) ? olen[idx + 1] : coltot[c];
-                const uint64_t gb = tb[c] + tiletot[c];
-                P.off[c][row0 + rb0 + r + 1] = (uint32_t)(gb + end);
-                if (end > ex) {
-                    const uint32_t d = desc[idx];
-                    const uint32_t s = d & 0x7FFFu, len = (d >> 15) & 0x7FFFu, lvl = d >> 30;
-                    uint8_t *dst = staged ? stage + stagebase[c] + ex : P.bytes[c] + gb + ex;
-                    uint64_t dv;
-                    bool b1, b2;
-                    if (len <= 16) {
-                        const uint4 w4 = lds_u128(sdata + s);
-                        cell_walk16<true>((uint64_t)w4.x | ((uint64_t)w4.y << 32), (uint64_t)w4.z | ((uint64_t)w4.w << 32), len,
-                                          lvl, nulcut, T_NONE, dst, dv, b1, b2);
+            for (int ps = 0; ps < RB_PASSES; ++ps) {
+                const uint32_t r = ps * 64 + lane;
+                uint32_t s = 0, len = 0, lvl = LVL_CHAR, flen = 0;
+                if (r < RBn) {
+                    const uint32_t idx = c * RB + r;
+                    bool found;
+                    if (csv) {
+                        const uint32_t d = desc[idx];
+                        s = d & 0x7FFFu;
+                        len = (d >> 15) & 0x7FFFu;
+                        found = (fmask[r * W + (c >> 5)] >> (c & 31)) & 1u;
                     } else {
-                        cell_walk<true>(sdata + s, len, lvl, nulcut, T_NONE, dst, dv, b1, b2);
+                        // getxmlbuffer's independent first-open / first-close search, then
+                        // splitbuffer's carry-forward: a missing tag keeps the nearest earlier
+                        // column's value, filtered by every column in between
+                        const uint32_t re = recend[r + 1];
+                        uint32_t o = evt[(2 * c) * RB + r], e = evt[(2 * c + 1) * RB + r];
+                        found = (o != NONE) & (e != NONE);
+                        uint32_t cs = c;
+                        lvl = clvl;
+                        bool have = found;
+                        if (!found && carry) {
+                            while (cs > 0) {
+                                --cs;
+                                o = evt[(2 * cs) * RB + r];
+                                e = evt[(2 * cs + 1) * RB + r];
+                                const uint32_t l2 = cols[cs].level;
+                                if (l2 > lvl) lvl = l2;
+                                if ((o != NONE) & (e != NONE)) {
+                                    have = true;
+                                    break;
+                                }
+                            }
+                        }
+                        if (have) {
+                            const uint32_t nml = cols[cs].namelen;
+                            const int cl = cols[cs].collen;
+                            s = o + nml + 2;
+                            int l = (int)e - (int)s;
+                            if (l < 0)
+                                l = (int)(re - s);  // close tag in front of the open tag: rest of record
+                            else if (cl > 0 && cl < l)
+                                l = cl;
+                            len = (uint32_t)l;
+                        }
+                        if (found) atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
+                    }
+                    const bool convert = typed != T_NONE && (found || nulcut);
+                    if (!convert && lvl == LVL_CHAR && !(nulcut && has_nul)) {
+                        flen = len;
+                        if (valp) valp[row0 + rb0 + r] = 0;
+                    } else {
+                        uint64_t value = 0;
+                        bool valid = false;
+                        const uint32_t ty = convert ? typed : (uint32_t)T_NONE;
+                        if (len <= 16) {
+                            const uint4 w4 = lds_u128(sdata + s);
+                            flen = cell_scan16<false>((uint64_t)w4.x | ((uint64_t)w4.y << 32),
+                                                      (uint64_t)w4.z | ((uint64_t)w4.w << 32), len, lvl, nulcut, ty,
+                                                      p10, nullptr, value, valid);
+                        } else {
+                            bool range = false;
+                            flen = cell_walk<false>(sdata + s, len, lvl, nulcut, ty, nullptr, value, valid, range);
+                            if (range) atomicOr(P.status, ST_NUMERIC_RANGE);
+                        }
+                        if (convert && valid) atomicOr(&vmask[r * W + (c >> 5)], 1u << (c & 31));
+                        if (valp) valp[row0 + rb0 + r] = convert ? value : 0;
                     }
                 }
+                const uint32_t incl = wave_incl_scan(flen);
+                cs_[ps] = s;
+                cl_[ps] = len;
+                cv_[ps] = lvl;
+                cf_[ps] = flen;
+                cx_[ps] = total + incl - flen;
+                total += __shfl(incl, 63, 64);
             }
-            __syncthreads();
-            STAMP(8);  // cell copy into staging + offsets
-            if (staged) {
-                for (uint32_t c = wave; c < ncols; c += BLOCK / 64) {
-                    const uint32_t tot = coltot[c];
-                    if (!tot) continue;
-                    const uint64_t gb = tb[c] + tiletot[c];
-                    uint8_t *dst = P.bytes[c] + gb;
-                    const uint8_t *src = stage + stagebase[c];
-                    uint32_t head = (uint32_t)((16 - (gb & 15)) & 15);
-                    if (head > tot) head = tot;
+            if (WRITE) {
+                const uint64_t gb = tb[c] + tiletot[c];
+                const uint32_t a = (uint32_t)(gb & 15);
+                const bool staged = a + total <= wstage_cap;
+                uint32_t *const offp = P.off[c];
+                uint8_t *const bytesp = P.bytes[c];
+#pragma unroll
+                for (int ps = 0; ps < RB_PASSES; ++ps) {
+                    const uint32_t r = ps * 64 + lane;
+                    if (r < RBn) {
+                        offp[row0 + rb0 + r + 1] = (uint32_t)(gb + cx_[ps] + cf_[ps]);
+                        if (cf_[ps]) {
+                            uint8_t *dst = staged ? wstage + a + cx_[ps] : bytesp + gb + cx_[ps];
+                            uint64_t dv;
+                            bool b1, b2;
+                            if (cl_[ps] <= 16) {
+                                const uint4 w4 = lds_u128(sdata + cs_[ps]);
+                                cell_scan16<true>((uint64_t)w4.x | ((uint64_t)w4.y << 32),
+                                                  (uint64_t)w4.z | ((uint64_t)w4.w << 32), cl_[ps], cv_[ps], nulcut,
+                                                  T_NONE, nullptr, dst, dv, b1);
+                            } else {
+                                cell_walk<true>(sdata + cs_[ps], cl_[ps], cv_[ps], nulcut, T_NONE, dst, dv, b1, b2);
+                            }
+                        }
+                    }
+                }
+                if (staged && total) {
+                    // the wave's own LDS writes are visible to it in program order
+                    uint8_t *dst = bytesp + gb;
+                    const uint8_t *src = wstage + a;
+                    uint32_t head = (16 - a) & 15;
+                    if (head > total) head = total;
                     if ((uint32_t)lane < head) dst[lane] = src[lane];
-                    const uint32_t body = (tot - head) / 16;
+                    const uint32_t body = (total - head) / 16;
                     for (uint32_t u = lane; u < body; u += 64)
                         *(uint4 *)(dst + head + u * 16) = *(const uint4 *)(src + head + u * 16);
                     const uint32_t done = head + body * 16;
-                    if ((uint32_t)lane < tot - done) dst[done + lane] = src[done + lane];
+                    if ((uint32_t)lane < total - done) dst[done + lane] = src[done + lane];
                 }
             }
-            if ((uint32_t)tid < RBn) {
-                const uint64_t row = row0 + rb0 + tid;
-                if (P.rec_off) P.rec_off[row + 1] = (uint64_t)(base_pos + (int64_t)recend[tid + 1] + 1);
-                for (uint32_t w = 0; w < W; ++w) {
-                    P.valid[row * W + w] = vmask[tid * W + w];
-                    P.found[row * W + w] = fmask[tid * W + w];
-                }
+            if (lane == 0) tiletot[c] += total;  // this wave owns column c
+        }
+        __syncthreads();
+        STAMP(5);  // cells: descriptors, lengths, values, staging, copy-out
+        if (WRITE && (uint32_t)tid < RBn) {
+            const uint64_t row = row0 + rb0 + tid;
+            if (P.rec_off) P.rec_off[row + 1] = (uint64_t)(base_pos + (int64_t)recend[tid + 1] + 1);
+            for (uint32_t w = 0; w < W; ++w) {
+                P.valid[row * W + w] = vmask[tid * W + w];
+                P.found[row * W + w] = fmask[tid * W + w];
             }
         }
         __syncthreads();
-        STAMP(9);  // copy-out + row outputs
-        for (uint32_t c = tid; c < ncols; c += BLOCK) tiletot[c] += coltot[c];
+        STAMP(9);  // row outputs
         if (tid == 0) recend[0] = recend[RBn];
         __syncthreads();
     }
