@@ -200,9 +200,9 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         L.data = o;
         o += round16(TILE + lbmax + DATA_SLACK);
         L.evlist = o;
-        L.evcap = 1536;
-        L.stage_cap = L.evcap * 4;
-        o += L.evcap * 4;
+        L.evcap = 2048;
+        L.stage_cap = L.evcap * 3;
+        o += L.evcap * 3;
         L.evt = o;
         o += round16(RB * (npat > ncols ? npat : ncols) * 4);
         L.recend = o;

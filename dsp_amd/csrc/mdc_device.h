@@ -87,7 +87,7 @@ static_assert(sizeof(SchemaHdr) % 16 == 0, "SchemaHdr must keep 16-byte alignmen
 // byte offsets of the LDS regions (computed on the host from the schema)
 struct LdsLayout {
     uint32_t data;    // TILE+LBMAX+DATA_SLACK bytes
-    uint32_t evlist;  // evcap u32: dense list of '<' events (position | rank<<16); later the cell staging area
+    uint32_t evlist;  // evcap x (u16 position + u8 batch rank) of the '<' events; later the cell staging area
     uint32_t evt;     // RB*max(npat,ncols) u32: first position of every tag pattern per record
                       // (delimited mode: the field descriptors)
     uint32_t recend;  // (RB+1) u32
@@ -99,7 +99,7 @@ struct LdsLayout {
     uint32_t total;
     uint32_t RB;         // records per batch (<= 256)
     uint32_t evcap;      // events per compaction window
-    uint32_t stage_cap;  // = evcap*4
+    uint32_t stage_cap;  // = evcap*3
     uint32_t lbmax;      // look-behind capacity in bytes (multiple of 16)
 };
 

@@ -123,7 +123,7 @@ __device__ __forceinline__ uint32_t cell_walk(const uint8_t *src, uint32_t len, 
     do {                                                                                           \
         if (threadIdx.x == 0) {                                                                    \
             const unsigned long long now_ = __builtin_readcyclecounter();                          \
-            atomicAdd(((unsigned long long *)P.status) + 2 + (i), now_ - stamp_t_);                \
+            atomicAdd(((unsigned long long *)P.status) + 2 + (WRITE ? 12 : 0) + (i), now_ - stamp_t_);                \
             stamp_t_ = now_;                                                                       \
         }                                                                                          \
     } while (0)
@@ -225,6 +225,33 @@ __device__ __forceinline__ void match_tag(const uint8_t *sdata, const SchemaHdr 
         slot = e.next;
         if (!slot) break;
     }
+}
+
+// Cells longer than 16 source bytes: filter only (length, or the surviving bytes).  Their
+// typed conversion is left to deferred_convert_kernel, which keeps the number parser for
+// arbitrary lengths out of this kernel.
+template <bool EMIT>
+__device__ __forceinline__ uint32_t cell_filter_long(const uint8_t *src, uint32_t len, uint32_t lvl, bool nulcut,
+                                                    uint8_t *dst) {
+    uint32_t out = 0;
+    for (uint32_t k = 0; k < len; ++k) {
+        const uint32_t b = src[k];
+        const bool dig = (b - '0') < 10u;
+        bool pass;
+        if (lvl == LVL_CHAR) {
+            if (nulcut && b == 0) break;
+            pass = true;
+        } else if (lvl == LVL_NUMBER) {
+            pass = dig | (b == '+') | (b == '-') | (b == '.');
+        } else {
+            pass = dig;
+        }
+        if (pass) {
+            if (EMIT) dst[out] = (uint8_t)b;
+            ++out;
+        }
+    }
+    return out;
 }
 
 // Cells of at most 16 source bytes, held in registers (lo = bytes 0..7, hi = bytes 8..15).
@@ -353,7 +380,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     const LdsLayout &L = P.L;
     uint8_t *sdata = smem + L.data;
-    uint32_t *evlist = (uint32_t *)(smem + L.evlist);
+    uint16_t *evpos = (uint16_t *)(smem + L.evlist);         // dense list of '<' events: LDS index
+    uint8_t *evrank = smem + L.evlist + 2 * L.evcap;         // ... and record rank within the batch
     uint32_t *evt = (uint32_t *)(smem + L.evt);
     uint32_t *desc = (uint32_t *)(smem + L.evt);  // delimited mode has no tag events: same space
     uint32_t *recend = (uint32_t *)(smem + L.recend);
@@ -384,12 +412,13 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         return make_uint4(w[0], w[1], w[2], w[3]);
     };
 
-    // ---- A. this lane's 64 tile bytes -> registers and LDS; first look-behind window; schema
-    uint4 v[4];
+    // ---- A. coalesced 16-byte loads of the tile, the first look-behind window and the schema
     {
-        const int jb = ts_li / CHUNK + tid * 4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (jb + k) * CHUNK < te_li ? load_chunk(jb + k) : make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < 4; ++k) {
+            const int j = ts_li / CHUNK + k * BLOCK + tid;
+            ((uint4 *)sdata)[j] = j * CHUNK < te_li ? load_chunk(j) : make_uint4(0, 0, 0, 0);
+        }
     }
     int loaded_lo = ts_li;
     if (tile_start > 0) {
@@ -402,8 +431,6 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         uint4 *s = (uint4 *)(smem + L.schema);
         for (uint32_t i = tid; i < P.schema_bytes / 16; i += BLOCK) s[i] = g[i];
         if (tid < MS_COUNT) ms[tid] = tid == MS_LAST ? NONE : 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ((uint4 *)sdata)[ts_li / CHUNK + tid * 4 + k] = v[k];
     }
     __syncthreads();
     const SchemaHdr *H = (const SchemaHdr *)(smem + L.schema);
@@ -415,65 +442,42 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     uint32_t *coltot = (uint32_t *)(smem + L.coltot);  // totals of the current batch
     uint32_t *tiletot = coltot + (ncols + 1);          // totals of the batches done so far
     for (uint32_t c = tid; c < ncols + 1; c += BLOCK) tiletot[c] = 0;
+    STAMP(0);  // loads
 
-    // look behind for the start of the first owned record
-    int s0_li = ts_li;
-    if (tile_start > 0) {
-        int new_lo = loaded_lo;
-        int hi_li = ts_li;
-        for (;;) {
-            for (int j = new_lo / CHUNK + tid; j < hi_li / CHUNK; j += BLOCK) {
-                const uint4 c4 = ((const uint4 *)sdata)[j];
-                uint32_t nl = mask16_eq(c4, 0x0A0A0A0Au);
-                while (nl) {
-                    const int b = __builtin_ctz(nl);
-                    nl &= nl - 1;
-                    const int p = j * CHUNK + b;
-                    // endbz bytes below the staged region are read from global memory
-                    bool t;
-                    if (p - (int)H->endbz_len >= new_lo) {
-                        t = is_term(sdata, H, base_pos, p);
-                    } else {
-                        const int el = (int)H->endbz_len;
-                        t = base_pos + p - el >= 0;
-                        for (int k = 0; t && k < el; ++k) {
-                            const int li = p - el + k;
-                            const uint32_t bb = li >= new_lo ? sdata[li] : P.data[base_pos + li];
-                            t = bb == H->endbz[k];
-                        }
+    // searches the staged chunks [lo, hi) for record terminators; keeps the last one
+    auto search_terminators = [&](int lo_li, int hi_li) {
+        for (int j = lo_li / CHUNK + tid; j < hi_li / CHUNK; j += BLOCK) {
+            const uint4 c4 = ((const uint4 *)sdata)[j];
+            uint32_t nl = mask16_eq(c4, 0x0A0A0A0Au);
+            while (nl) {
+                const int b = __builtin_ctz(nl);
+                nl &= nl - 1;
+                const int p = j * CHUNK + b;
+                bool t;
+                if (p - (int)H->endbz_len >= lo_li) {
+                    t = is_term(sdata, H, base_pos, p);
+                } else {  // endbz bytes below the staged region are read from global memory
+                    const int el = (int)H->endbz_len;
+                    t = base_pos + p - el >= 0;
+                    for (int k = 0; t && k < el; ++k) {
+                        const int li = p - el + k;
+                        const uint32_t bb = li >= lo_li ? sdata[li] : P.data[base_pos + li];
+                        t = bb == H->endbz[k];
                     }
-                    if (t) atomicMax((int *)&ms[MS_LAST], p);
                 }
+                if (t) atomicMax((int *)&ms[MS_LAST], p);
             }
-            __syncthreads();
-            const int last = (int)ms[MS_LAST];
-            loaded_lo = new_lo;
-            if (last >= 0) {
-                s0_li = last + 1;
-                break;
-            }
-            if (base_pos + new_lo == 0) {  // reached the start of the input
-                s0_li = new_lo;
-                break;
-            }
-            if (new_lo == 0) {  // record longer than the look-behind window
-                if (tid == 0) atomicOr(P.status, ST_RECORD_TOO_LONG);
-                s0_li = 0;
-                break;
-            }
-            hi_li = new_lo;
-            new_lo = hi_li - LB_STEP < li_min ? li_min : hi_li - LB_STEP;
-            for (int j = new_lo / CHUNK + tid; j < hi_li / CHUNK; j += BLOCK) ((uint4 *)sdata)[j] = load_chunk(j);
-            __syncthreads();
         }
-    }
-    STAMP(0);  // load + look-behind
+    };
 
-    // ---- B. classify the lane's 64 bytes: terminators, '<' (or separator starts), NUL
+    // ---- B. classify this lane's 64 bytes: terminators, '<', NUL; first look-behind search
     const int my_li = ts_li + tid * 64;
-    uint64_t tm = 0;   // record terminators
-    uint64_t em;       // event candidates: '<' in XML mode (delimited mode does not use events)
+    uint64_t tm = 0;  // record terminators
+    uint64_t em;      // event candidates: '<' in XML mode (delimited mode does not use events)
     {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ((const uint4 *)sdata)[my_li / CHUNK + k];
         uint64_t nlm = mask64_eq(v, 0x0A0A0A0Au);
         em = csv ? 0 : mask64_eq(v, 0x3C3C3C3Cu);
         if (mask64_eq(v, 0)) ms[MS_HASNUL] = 1;
@@ -489,6 +493,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             if (is_term(sdata, H, base_pos, my_li + b)) tm |= 1ull << b;
         }
     }
+    if (tile_start > 0) search_terminators(loaded_lo, ts_li);
     uint32_t rank_base, ev_base, nrec, nev_tile;
     {
         const uint32_t mine = ((uint32_t)__builtin_popcountll(tm) << 16) | (uint32_t)__builtin_popcountll(em);
@@ -506,6 +511,33 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         ev_base = base & 0xFFFFu;
         nrec = tot >> 16;
         nev_tile = tot & 0xFFFFu;
+    }
+    // start of the first owned record: behind the last terminator in front of the tile
+    int s0_li = ts_li;
+    if (tile_start > 0) {
+        for (;;) {
+            const int last = (int)ms[MS_LAST];
+            if (last >= 0) {
+                s0_li = last + 1;
+                break;
+            }
+            if (base_pos + loaded_lo == 0) {  // reached the start of the input
+                s0_li = loaded_lo;
+                break;
+            }
+            if (loaded_lo == 0) {  // the record starts in front of the look-behind capacity
+                if (tid == 0) atomicOr(P.status, ST_RECORD_TOO_LONG);
+                s0_li = 0;
+                break;
+            }
+            // rare: extend the staged region backwards and search it
+            const int hi_li = loaded_lo;
+            loaded_lo = hi_li - LB_STEP < li_min ? li_min : hi_li - LB_STEP;
+            for (int j = loaded_lo / CHUNK + tid; j < hi_li / CHUNK; j += BLOCK) ((uint4 *)sdata)[j] = load_chunk(j);
+            __syncthreads();
+            search_terminators(loaded_lo, hi_li);
+            __syncthreads();
+        }
     }
     const bool has_nul = ms[MS_HASNUL] != 0;
     const uint32_t RB = L.RB, EVCAP = L.evcap;
@@ -566,7 +598,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                         m &= m - 1;
                         if (idx >= w0 && idx < w0 + EVCAP) {
                             const uint32_t r = rank_base + (uint32_t)__builtin_popcountll(tm & ((1ull << b) - 1));
-                            evlist[idx - w0] = (uint32_t)(my_li + b) | (r << 16);
+                            evpos[idx - w0] = (uint16_t)(my_li + b);
+                            evrank[idx - w0] = (r >= rb0 && r < rb0 + RBn) ? (uint8_t)(r - rb0) : (uint8_t)0xFF;
                         }
                         ++idx;
                     }
@@ -574,9 +607,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 __syncthreads();
                 const uint32_t cnt = nev_tile - w0 < EVCAP ? nev_tile - w0 : EVCAP;
                 for (uint32_t e = tid; e < cnt; e += BLOCK) {
-                    const uint32_t ev = evlist[e];
-                    const uint32_t q = ev & 0xFFFFu, r = ev >> 16;
-                    if (r >= rb0 && r < rb0 + RBn) match_tag(sdata, H, cols, ht, q, evt, r - rb0, RB);
+                    const uint32_t q = evpos[e], rl = evrank[e];
+                    if (rl != 0xFFu) match_tag(sdata, H, cols, ht, q, evt, rl, RB);
                 }
                 __syncthreads();
             }
@@ -653,6 +685,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         // ---- E-H. one wave per column, one lane per record; everything about a column (cell
         // descriptors, lengths, typed values, offsets, staging, copy-out) stays inside the wave,
         // so no block barrier is needed until the row outputs
+        bool deferred = false;
         uint8_t *const wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
         const uint32_t wstage_cap = L.stage_cap / (BLOCK / 64);
         for (uint32_t c = wave; c < ncols; c += BLOCK / 64) {
@@ -723,9 +756,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                                                       (uint64_t)w4.z | ((uint64_t)w4.w << 32), len, lvl, nulcut, ty,
                                                       p10, nullptr, value, valid);
                         } else {
-                            bool range = false;
-                            flen = cell_walk<false>(sdata + s, len, lvl, nulcut, ty, nullptr, value, valid, range);
-                            if (range) atomicOr(P.status, ST_NUMERIC_RANGE);
+                            flen = cell_filter_long<false>(sdata + s, len, lvl, nulcut, nullptr);
+                            if (convert) deferred = true;  // value and valid bit come from the second stage
                         }
                         if (convert && valid) atomicOr(&vmask[r * W + (c >> 5)], 1u << (c & 31));
                         if (valp) valp[row0 + rb0 + r] = convert ? value : 0;
@@ -753,14 +785,14 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                         if (cf_[ps]) {
                             uint8_t *dst = staged ? wstage + a + cx_[ps] : bytesp + gb + cx_[ps];
                             uint64_t dv;
-                            bool b1, b2;
+                            bool b1;
                             if (cl_[ps] <= 16) {
                                 const uint4 w4 = lds_u128(sdata + cs_[ps]);
                                 cell_scan16<true>((uint64_t)w4.x | ((uint64_t)w4.y << 32),
                                                   (uint64_t)w4.z | ((uint64_t)w4.w << 32), cl_[ps], cv_[ps], nulcut,
                                                   T_NONE, nullptr, dst, dv, b1);
                             } else {
-                                cell_walk<true>(sdata + cs_[ps], cl_[ps], cv_[ps], nulcut, T_NONE, dst, dv, b1, b2);
+                                cell_filter_long<true>(sdata + cs_[ps], cl_[ps], cv_[ps], nulcut, dst);
                             }
                         }
                     }
@@ -781,6 +813,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             }
             if (lane == 0) tiletot[c] += total;  // this wave owns column c
         }
+        if (WRITE && deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
         __syncthreads();
         STAMP(5);  // cells: descriptors, lengths, values, staging, copy-out
         if (WRITE && (uint32_t)tid < RBn) {
@@ -846,12 +879,15 @@ __global__ __launch_bounds__(256) void fixed_stride_kernel(const uint32_t *off, 
     }
 }
 
-// Second stage of the typed conversion: cells whose text is beyond the 128-bit exact range
-// (flagged ST_NUMERIC_RANGE by the tile kernel, which left them invalid) are converted with
-// multi-precision arithmetic, reading the cell text back from the column arena.
-__global__ __launch_bounds__(256) void long_float_kernel(const uint8_t *schema, uint32_t *const *off,
-                                                         uint8_t *const *bytes, uint64_t *const *val,
-                                                         uint32_t *valid, const uint32_t *found, uint64_t rows) {
+// Second stage of the typed conversion.  The tile kernel converts cells of up to 16 source
+// bytes itself and leaves the others invalid (raising ST_NUMERIC_RANGE).  This kernel visits
+// every typed cell whose valid bit is clear, reads the cell text back from the column arena and
+// runs the general parser: 128-bit arithmetic up to 38 digits (mdc_numparse.h), multi-precision
+// beyond (mdc_bignum.h).  Re-converting a cell that was legitimately invalid yields invalid
+// again, so the criterion needs no extra bookkeeping.
+__global__ __launch_bounds__(256) void deferred_convert_kernel(const uint8_t *schema, uint32_t *const *off,
+                                                               uint8_t *const *bytes, uint64_t *const *val,
+                                                               uint32_t *valid, const uint32_t *found, uint64_t rows) {
     const SchemaHdr *H = (const SchemaHdr *)schema;
     const DevCol *cols = (const DevCol *)(H + 1);
     const uint32_t ncols = H->ncols, W = H->words;
@@ -862,17 +898,18 @@ __global__ __launch_bounds__(256) void long_float_kernel(const uint8_t *schema, 
         const uint64_t r = i / ncols;
         const uint32_t c = (uint32_t)(i - r * ncols);
         const uint32_t typed = cols[c].typed;
-        if (typed != T_F64 && typed != T_F32) continue;
-        if (!always && !((found[r * W + (c >> 5)] >> (c & 31)) & 1u)) continue;
+        if (typed == T_NONE) continue;
+        const uint32_t bit = 1u << (c & 31);
+        if (valid[r * W + (c >> 5)] & bit) continue;
+        if (!always && !(found[r * W + (c >> 5)] & bit)) continue;
         const uint32_t o = off[c][r], len = off[c][r + 1] - o;
-        if (len <= 38) continue;
         uint64_t v = 0;
         bool ok = false, range = false;
         cell_walk<false>(bytes[c] + o, len, LVL_CHAR, false, typed, nullptr, v, ok, range);
-        if (!range) continue;
-        if (big_convert(bytes[c] + o, len, typed == T_F64, v)) {
+        if (range) ok = big_convert(bytes[c] + o, len, typed == T_F64, v);
+        if (ok) {
             val[c][r] = v;
-            atomicOr(&valid[r * W + (c >> 5)], 1u << (c & 31));
+            atomicOr(&valid[r * W + (c >> 5)], bit);
         }
     }
 }
@@ -887,7 +924,7 @@ hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_
     uint64_t total = rows * ncols;
     uint32_t blocks = (uint32_t)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(long_float_kernel, dim3(blocks), dim3(256), 0, stream, schema, off, bytes, val, valid, found,
+    hipLaunchKernelGGL(deferred_convert_kernel, dim3(blocks), dim3(256), 0, stream, schema, off, bytes, val, valid, found,
                        rows);
     return hipGetLastError();
 }

@@ -20,15 +20,17 @@ else:
     data, rows = gen.mind_csv(nbytes=nbytes)
     p = capi.Parser.csv(",", 10, typed=schema.MIND_CSV_TYPED)
 d = capi.DeviceBuffer(data)
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 24)()
 p.parse_device(d.ptr, d.n).free()
-L.mdc_debug_phase_counters(p.h, buf, 16, 1)
+L.mdc_debug_phase_counters(p.h, buf, 24, 1)
 p.parse_device(d.ptr, d.n).free()
-L.mdc_debug_phase_counters(p.h, buf, 16, 1)
+L.mdc_debug_phase_counters(p.h, buf, 24, 1)
 names = ["load+lookbehind", "terminators+rank", "clears", "events", "record->desc", "measure+convert",
          "column scans", "stage bases", "cell copy", "copy-out+rows"]
-tot = sum(buf[i] for i in range(10))
 t = p.timing()
 print(f"rows={rows} count_ms={t.count_ms:.3f} write_ms={t.write_ms:.3f}")
-for i, n in enumerate(names):
-    print(f"  {n:20s} {buf[i]:>16d}  {100.0 * buf[i] / tot:5.1f}%")
+for label, base in (("count pass", 0), ("write pass", 12)):
+    tot = sum(buf[base + i] for i in range(10)) or 1
+    print(label, "cycles/tile =", tot // max(t.tiles, 1))
+    for i, n in enumerate(names):
+        print(f"  {n:20s} {buf[base + i]:>16d}  {100.0 * buf[base + i] / tot:5.1f}%")
