@@ -48,12 +48,13 @@ def build_parse(force=False):
     return target
 
 
-def build_diag(force=True):
-    """Diagnostic variant with per-phase cycle counters (never used by tests or bench)."""
-    target = os.path.join(HERE, "libmdc_parse_diag.so")
+def build_diag(force=True, define="MDC_PHASE_TIMING", name="libmdc_parse_diag.so"):
+    """Diagnostic variants (never used by tests or bench): MDC_PHASE_TIMING adds per-phase cycle
+    counters, MDC_ABLATE lets MDC_DEBUG_SKIP switch phases off."""
+    target = os.path.join(HERE, name)
     srcs = [os.path.join(CSRC, f) for f in ("mdc_kernels.hip", "mdc_abi.cpp")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    _run([hipcc] + HIPCC_FLAGS + ["-DMDC_PHASE_TIMING", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+    _run([hipcc] + HIPCC_FLAGS + ["-D" + define, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
                                   "-x", "hip"] + srcs + ["-o", target])
     return target
 

@@ -193,7 +193,7 @@ static uint32_t round16(uint32_t v) { return (v + 15) & ~15u; }
 
 static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32_t blob_bytes, uint32_t lbmax,
                            LdsLayout &L) {
-    uint32_t RB = 120;
+    uint32_t RB = 112;
     for (;;) {
         uint32_t o = 0;
         L.lbmax = lbmax;
@@ -213,6 +213,8 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         o += round16(RB * words * 4);
         L.coltot = o;
         o += round16(2 * (ncols + 1) * 4);
+        L.dbm = o;
+        o += round16((LB_FIRST / 64 + BLOCK + 1) * 8);
         L.schema = o;
         o += round16(blob_bytes);
         L.misc = o;
@@ -220,13 +222,13 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         L.total = o;
         L.RB = RB;
         if (o <= 40 * 1024 || RB <= 8) break;
-        if (RB > 64 && lbmax > 2048) break;  // the larger look-behind configurations trade occupancy
+        if (RB > 64 && lbmax > 1536) break;  // the larger look-behind configurations trade occupancy
         RB = RB > 16 ? RB - 8 : RB / 2;
     }
 }
 
 // look-behind capacities tried in turn when a record does not fit (fewer blocks per CU each)
-static const uint32_t LB_LEVELS[3] = {2048, 8192, LBMAX};
+static const uint32_t LB_LEVELS[3] = {1536, 8192, LBMAX};
 
 static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *sep, int bdelspace) {
     const uint32_t ncols = (uint32_t)p->ncols;
@@ -540,6 +542,9 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     P.tile_counts = p->d_counts;
     P.tile_base = p->d_base;
     P.status = p->d_status;
+#ifdef MDC_ABLATE
+    if (const char *dbg = getenv("MDC_DEBUG_SKIP")) P.debug = (uint32_t)atoi(dbg);
+#endif
 
     hipStream_t s = d->stream;
     // Sizing pass.  The look-behind capacity starts at the level that fitted the previous

@@ -94,6 +94,7 @@ struct LdsLayout {
     uint32_t vmask;   // RB*words u32
     uint32_t fmask;   // RB*words u32
     uint32_t coltot;  // 2*(ncols+1) u32: batch totals, tile totals
+    uint32_t dbm;     // (LB_FIRST/64 + BLOCK + 1) u64: digit bitmap of the tile and the first look-behind window
     uint32_t schema;  // schema blob
     uint32_t misc;    // block-wide scalars
     uint32_t total;
@@ -121,6 +122,7 @@ struct TileParams {
     uint32_t *valid;             // rows*words
     uint32_t *found;             // rows*words
     uint32_t *status;
+    uint32_t debug;  // diagnostic builds only: phases to skip (ablation timing)
 };
 
 }  // namespace mdc

@@ -118,6 +118,11 @@ __device__ __forceinline__ uint32_t cell_walk(const uint8_t *src, uint32_t len, 
 // Diagnostic build only (-DMDC_PHASE_TIMING): thread 0 of every block adds the cycles spent
 // since the previous stamp to a per-phase counter that sits behind the status word.  The
 // counters are read by nothing in the kernel.
+#ifdef MDC_ABLATE
+#define SKIP(bit) (P.debug & (bit))
+#else
+#define SKIP(bit) false
+#endif
 #ifdef MDC_PHASE_TIMING
 #define STAMP(i)                                                                                   \
     do {                                                                                           \
@@ -368,6 +373,197 @@ __device__ __forceinline__ uint32_t cell_scan16(uint64_t lo, uint64_t hi, uint32
     return out;
 }
 
+// ---------------------------------------------------------------------------------------
+// Fast cell path.  A 64-bit digit bitmap per 64 tile bytes (made with the other SWAR masks
+// during classification) tells, for any cell of up to 16 source bytes, which bytes are
+// digits.  Cells with at most two other bytes (a sign, a decimal point, one stray byte: all
+// well-formed numbers and dates) are measured, filtered and converted without any per-byte
+// loop; everything else takes cell_scan16 / cell_filter_long.
+
+// exact per-byte digit flags (0x80 where the byte is '0'..'9')
+__device__ __forceinline__ uint32_t digit_flags(uint32_t w) {
+    const uint32_t y = w ^ 0x30303030u;
+    const uint32_t f = ((y & 0x7F7F7F7Fu) + 0x76767676u) | y;
+    return ~f & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t digit_mask16(const uint4 &v) {
+    return pack4(digit_flags(v.x)) | (pack4(digit_flags(v.y)) << 4) | (pack4(digit_flags(v.z)) << 8) |
+           (pack4(digit_flags(v.w)) << 12);
+}
+__device__ __forceinline__ uint64_t digit_mask64(const uint4 (&v)[4]) {
+    const uint64_t lo = (uint64_t)digit_mask16(v[0]) | ((uint64_t)digit_mask16(v[1]) << 16);
+    const uint64_t hi = (uint64_t)digit_mask16(v[2]) | ((uint64_t)digit_mask16(v[3]) << 16);
+    return lo | (hi << 32);
+}
+
+// byte p (0..15) of the 16-byte window (lo, hi)
+__device__ __forceinline__ uint32_t win_byte(uint64_t lo, uint64_t hi, uint32_t p) {
+    const uint64_t w = p < 8 ? lo : hi;
+    return (uint32_t)(w >> (8 * (p & 7))) & 0xFFu;
+}
+// removes byte p from the window (bytes above it move down by one)
+__device__ __forceinline__ void win_remove(uint64_t &lo, uint64_t &hi, uint32_t p) {
+    const uint64_t slo = (lo >> 8) | (hi << 56), shi = hi >> 8;
+    const uint64_t blo = p < 8 ? ((1ull << (8 * p)) - 1) : ~0ull;
+    const uint64_t bhi = p < 8 ? 0ull : ((1ull << (8 * (p - 8))) - 1);
+    lo = (lo & blo) | (slo & ~blo);
+    hi = (hi & bhi) | (shi & ~bhi);
+}
+// keeps bytes 0..n-1 of the window (n <= 16), zeroes the rest
+__device__ __forceinline__ void win_keep(uint64_t &lo, uint64_t &hi, uint32_t n) {
+    lo &= n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1);
+    hi &= n >= 16 ? ~0ull : n <= 8 ? 0ull : ((1ull << (8 * (n - 8))) - 1);
+}
+// four decimal digit values in the bytes of w (byte 0 most significant) -> 0..9999
+__device__ __forceinline__ uint32_t parse4(uint32_t w) {
+    const uint32_t t = __umul24(w & 0x000F000Fu, 10u) + ((w >> 8) & 0x000F000Fu);
+    return __umul24(t & 0xFFFFu, 100u) + (t >> 16);
+}
+
+// Returns false when the cell needs the general path.  On success: flen = cell length, (elo,
+// ehi) = the cell's bytes (window with the filtered-out bytes removed), and for typed != NONE
+// the converted value / validity.  D16 = digit bits of the window's bytes.
+__device__ __forceinline__ bool cell_fast(uint64_t lo, uint64_t hi, uint32_t len, uint32_t D16, uint32_t lvl,
+                                          uint32_t typed, const double *p10, uint32_t &flen, uint64_t &value,
+                                          bool &valid, uint64_t &elo, uint64_t &ehi) {
+    const uint32_t Lm = (1u << len) - 1;  // len <= 16
+    const uint32_t D = D16 & Lm, N = ~D16 & Lm;
+    const uint32_t N2 = N & (N - 1);
+    const bool e1 = N != 0, e2 = N2 != 0;
+    const uint32_t p1 = e1 ? (uint32_t)__builtin_ctz(N) : 16u, p2 = e2 ? (uint32_t)__builtin_ctz(N2) : 16u;
+    const uint32_t c1 = win_byte(lo, hi, p1 & 15), c2 = win_byte(lo, hi, p2 & 15);
+    const bool s1 = (c1 == '+') | (c1 == '-'), s2 = (c2 == '+') | (c2 == '-');
+    const bool d1 = c1 == '.', d2 = c2 == '.';
+    // picknumber's filter for the cell's level
+    const bool P1 = e1 & (lvl == LVL_CHAR ? true : lvl == LVL_NUMBER ? (s1 | d1) : false);
+    const bool P2 = e2 & (lvl == LVL_CHAR ? true : lvl == LVL_NUMBER ? (s2 | d2) : false);
+    flen = len - ((e1 & !P1) ? 1 : 0) - ((e2 & !P2) ? 1 : 0);
+    elo = lo;
+    ehi = hi;
+    if (e2 & !P2) win_remove(elo, ehi, p2);
+    if (e1 & !P1) win_remove(elo, ehi, p1);
+    const bool ok = (N2 & (N2 - 1)) == 0;  // at most two non-digit bytes
+    valid = false;
+    value = 0;
+    if (typed == T_NONE) return ok;
+    // the conversion's own filter, then the [+-]digits[.digits] prefix grammar
+    const bool isfloat = typed == T_F64;
+    const bool issigned = (typed == T_I32) | (typed == T_I64) | isfloat;
+    const bool Q1 = P1 & ((s1 & issigned) | (d1 & isfloat));
+    const bool Q2 = P2 & ((s2 & issigned) | (d2 & isfloat));
+    uint32_t stop = 16, dotp = 16;
+    bool neg = false;
+    if (Q1) {
+        if (s1) {
+            if ((D & ((1u << p1) - 1)) == 0)
+                neg = c1 == '-';
+            else
+                stop = p1;
+        } else {
+            dotp = p1;
+        }
+    }
+    if (Q2 & (p2 < stop)) {
+        if (s2) {
+            if (!Q1 && (D & ((1u << p2) - 1)) == 0)
+                neg = c2 == '-';
+            else
+                stop = p2;
+        } else {
+            if (dotp == 16)
+                dotp = p2;
+            else
+                stop = p2;
+        }
+    }
+    const uint32_t DL = D & ((1u << stop) - 1);  // stop == 16 keeps all 16 bits
+    if (DL == 0) return ok;                        // no digit: the reference overload returns false
+    const uint32_t nd = (uint32_t)__builtin_popcount(DL);
+    const uint32_t k10 = dotp < 16 ? (uint32_t)__builtin_popcount(DL >> (dotp + 1)) : 0u;
+    // the digits, contiguous from byte 0
+    uint64_t xlo = lo, xhi = hi;
+    win_keep(xlo, xhi, stop < len ? stop : len);
+    if (e2 & (p2 < stop)) win_remove(xlo, xhi, p2);
+    if (e1 & (p1 < stop)) win_remove(xlo, xhi, p1);
+    // right-align the nd digits in a 16-digit field and convert four at a time
+    const uint32_t sh = 8 * (16 - nd);  // 0..120
+    uint64_t ylo, yhi;
+    if (sh >= 64) {
+        yhi = xlo << (sh - 64);
+        ylo = 0;
+    } else {
+        yhi = sh ? (xhi << sh) | (xlo >> (64 - sh)) : xhi;
+        ylo = xlo << sh;
+    }
+    const uint32_t hi8 = parse4((uint32_t)ylo) * 10000u + parse4((uint32_t)(ylo >> 32));
+    const uint32_t lo8 = parse4((uint32_t)yhi) * 10000u + parse4((uint32_t)(yhi >> 32));
+    const uint64_t m = (uint64_t)hi8 * 100000000ull + lo8;
+    switch (typed) {
+    case T_I32:
+        if (m <= (neg ? 0x80000000ull : 0x7fffffffull)) {
+            valid = true;
+            value = neg ? (uint64_t)(-(int64_t)m) : m;
+        }
+        break;
+    case T_U32:
+        if (m <= 0x7fffffffull) {
+            valid = true;
+            value = m;
+        }
+        break;
+    case T_I64:
+    case T_U64:  // at most 16 digits: always in range
+        valid = true;
+        value = neg ? (uint64_t)0 - m : m;
+        break;
+    default:  // T_F64
+        valid = true;
+        if (m == 0) {
+            value = neg ? 1ull << 63 : 0;
+        } else if (m < (1ull << 53)) {
+            const double x = (double)m / p10[k10];  // both exact (k10 <= 16): one correctly rounded division
+            value = (uint64_t)__double_as_longlong(neg ? -x : x);
+        } else {
+            int e;
+            uint64_t mant;
+            u128 M;
+            M.hi = 0;
+            M.lo = m;
+            div_round(M, k10, 53, e, mant);
+            value = ((uint64_t)neg << 63) | ((uint64_t)(e + 1023) << 52) | (mant & ((1ull << 52) - 1));
+        }
+        break;
+    }
+    return ok;
+}
+
+// stores the first n (<= 16) bytes of the window at dst with at most five unaligned stores
+__device__ __forceinline__ void win_store(uint8_t *dst, uint64_t lo, uint64_t hi, uint32_t n) {
+    if (n & 16) {
+        __builtin_memcpy(dst, &lo, 8);
+        __builtin_memcpy(dst + 8, &hi, 8);
+        return;
+    }
+    if (n & 8) {
+        __builtin_memcpy(dst, &lo, 8);
+        dst += 8;
+        lo = hi;
+    }
+    if (n & 4) {
+        const uint32_t w = (uint32_t)lo;
+        __builtin_memcpy(dst, &w, 4);
+        dst += 4;
+        lo >>= 32;
+    }
+    if (n & 2) {
+        const uint16_t w = (uint16_t)lo;
+        __builtin_memcpy(dst, &w, 2);
+        dst += 2;
+        lo >>= 16;
+    }
+    if (n & 1) *dst = (uint8_t)lo;
+}
+
 constexpr int RB_PASSES = 2;  // records per batch <= 64 * RB_PASSES
 
 // descriptor of one cell: source start (15 bits) | source length (15 bits) | filter level (2)
@@ -389,6 +585,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     uint32_t *fmask = (uint32_t *)(smem + L.fmask);
     uint8_t *stage = smem + L.evlist;  // the event list is dead when cells are staged
     uint32_t *ms = (uint32_t *)(smem + L.misc);
+    uint64_t *dbm = (uint64_t *)(smem + L.dbm);  // digit bitmap: bit (li - bm_lo) of the LDS image
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -402,6 +599,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     const int ts_li = LB;
     const int te_li = LB + (int)(tile_end - tile_start);
     const int li_min = base_pos < 0 ? (int)(-base_pos) : 0;
+    const int bm_lo = ts_li - LB_FIRST;  // first LDS index covered by the digit bitmap
 
     auto load_chunk = [&](int j) -> uint4 {  // 16-byte chunk j of the LDS image, from global memory
         const int64_t pos = base_pos + (int64_t)j * CHUNK;
@@ -481,6 +679,13 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         uint64_t nlm = mask64_eq(v, 0x0A0A0A0Au);
         em = csv ? 0 : mask64_eq(v, 0x3C3C3C3Cu);
         if (mask64_eq(v, 0)) ms[MS_HASNUL] = 1;
+        dbm[LB_FIRST / 64 + tid] = digit_mask64(v);
+        if (tile_start > 0 && tid < LB_FIRST / 64) {  // and for the first look-behind window
+            uint4 u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = ((const uint4 *)sdata)[(bm_lo + tid * 64) / CHUNK + k];
+            dbm[tid] = digit_mask64(u);
+        }
         const int lim = te_li - my_li;  // bytes of this lane that belong to the input
         if (lim < 64) {
             const uint64_t keep = lim <= 0 ? 0 : (~0ull >> (64 - lim));
@@ -574,7 +779,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         __syncthreads();
         STAMP(2);  // clears
 
-        if (!csv) {
+        if (!csv && !SKIP(1)) {
             // ---- C. the first record's events in the look-behind region (first batch only)
             if (rb0 == 0) {
                 for (int j = jlb0 + tid; j < jlb1; j += BLOCK) {
@@ -688,16 +893,20 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         bool deferred = false;
         uint8_t *const wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
         const uint32_t wstage_cap = L.stage_cap / (BLOCK / 64);
-        for (uint32_t c = wave; c < ncols; c += BLOCK / 64) {
+        for (uint32_t c = wave; c < ncols && !SKIP(2); c += BLOCK / 64) {
             const uint32_t typed = cols[c].typed;
             const uint32_t clvl = cols[c].level;
             uint64_t *const valp = (WRITE && typed != T_NONE) ? P.val[c] : nullptr;
             uint32_t cs_[RB_PASSES], cl_[RB_PASSES], cv_[RB_PASSES], cf_[RB_PASSES], cx_[RB_PASSES];
+            uint64_t clo_[RB_PASSES], chi_[RB_PASSES];  // fast cells: their bytes, ready to store
+            bool cfast_[RB_PASSES];
             uint32_t total = 0;
 #pragma unroll
             for (int ps = 0; ps < RB_PASSES; ++ps) {
                 const uint32_t r = ps * 64 + lane;
                 uint32_t s = 0, len = 0, lvl = LVL_CHAR, flen = 0;
+                uint64_t elo = 0, ehi = 0;
+                bool fast = false;
                 if (r < RBn) {
                     const uint32_t idx = c * RB + r;
                     bool found;
@@ -743,27 +952,43 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                         if (found) atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
                     }
                     const bool convert = typed != T_NONE && (found || nulcut);
-                    if (!convert && lvl == LVL_CHAR && !(nulcut && has_nul)) {
-                        flen = len;
-                        if (valp) valp[row0 + rb0 + r] = 0;
-                    } else {
-                        uint64_t value = 0;
-                        bool valid = false;
-                        const uint32_t ty = convert ? typed : (uint32_t)T_NONE;
-                        if (len <= 16) {
-                            const uint4 w4 = lds_u128(sdata + s);
-                            flen = cell_scan16<false>((uint64_t)w4.x | ((uint64_t)w4.y << 32),
-                                                      (uint64_t)w4.z | ((uint64_t)w4.w << 32), len, lvl, nulcut, ty,
-                                                      p10, nullptr, value, valid);
-                        } else {
-                            flen = cell_filter_long<false>(sdata + s, len, lvl, nulcut, nullptr);
-                            if (convert) deferred = true;  // value and valid bit come from the second stage
+                    const uint32_t ty = (WRITE && convert) ? typed : (uint32_t)T_NONE;  // sizing needs lengths only
+                    uint64_t value = 0;
+                    bool valid = false;
+                    if (len <= 16 && (int)s >= bm_lo) {
+                        const uint4 w4 = lds_u128(sdata + s);
+                        const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
+                        const uint64_t hi = (uint64_t)w4.z | ((uint64_t)w4.w << 32);
+                        const bool cutting = lvl == LVL_CHAR && nulcut && has_nul;
+                        if (lvl == LVL_CHAR && ty == T_NONE && !cutting) {
+                            flen = len;
+                            elo = lo;
+                            ehi = hi;
+                            fast = true;
+                        } else if (!cutting && ty != T_F32 && ty != T_BOOL) {
+                            const uint32_t boff = (uint32_t)((int)s - bm_lo);
+                            uint32_t dbits;
+                            __builtin_memcpy(&dbits, (const uint8_t *)dbm + (boff >> 3), 4);
+                            fast = cell_fast(lo, hi, len, dbits >> (boff & 7), lvl, ty, p10, flen, value, valid, elo, ehi);
                         }
-                        if (convert && valid) atomicOr(&vmask[r * W + (c >> 5)], 1u << (c & 31));
-                        if (valp) valp[row0 + rb0 + r] = convert ? value : 0;
+                        if (!fast)
+                            flen = cell_scan16<false>(lo, hi, len, lvl, nulcut, ty, p10, nullptr, value, valid);
+                    } else if (len <= 16) {
+                        const uint4 w4 = lds_u128(sdata + s);
+                        flen = cell_scan16<false>((uint64_t)w4.x | ((uint64_t)w4.y << 32),
+                                                  (uint64_t)w4.z | ((uint64_t)w4.w << 32), len, lvl, nulcut, ty, p10,
+                                                  nullptr, value, valid);
+                    } else {
+                        flen = cell_filter_long<false>(sdata + s, len, lvl, nulcut, nullptr);
+                        if (ty != T_NONE) deferred = true;  // value and valid bit come from the second stage
                     }
+                    if (WRITE && convert && valid) atomicOr(&vmask[r * W + (c >> 5)], 1u << (c & 31));
+                    if (valp) valp[row0 + rb0 + r] = value;
                 }
                 const uint32_t incl = wave_incl_scan(flen);
+                clo_[ps] = elo;
+                chi_[ps] = ehi;
+                cfast_[ps] = fast;
                 cs_[ps] = s;
                 cl_[ps] = len;
                 cv_[ps] = lvl;
@@ -786,7 +1011,9 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                             uint8_t *dst = staged ? wstage + a + cx_[ps] : bytesp + gb + cx_[ps];
                             uint64_t dv;
                             bool b1;
-                            if (cl_[ps] <= 16) {
+                            if (cfast_[ps]) {
+                                win_store(dst, clo_[ps], chi_[ps], cf_[ps]);
+                            } else if (cl_[ps] <= 16) {
                                 const uint4 w4 = lds_u128(sdata + cs_[ps]);
                                 cell_scan16<true>((uint64_t)w4.x | ((uint64_t)w4.y << 32),
                                                   (uint64_t)w4.z | ((uint64_t)w4.w << 32), cl_[ps], cv_[ps], nulcut,

@@ -1,0 +1,27 @@
+"""Diagnostic: kernel time with phases switched off (libmdc_parse_ablate.so, MDC_DEBUG_SKIP bits:
+1 = tag events, 2 = cells).  Outputs are wrong by construction; only the times matter."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    sys.path.insert(0, ROOT)
+    from dsp_amd import capi, gen, schema
+    capi.LIB_PATH = os.path.join(ROOT, "dsp_amd", "libmdc_parse_ablate.so")
+    data, rows = gen.mind_xml(nbytes=1 << 30)
+    p = capi.Parser.xml(schema.ZHOBTMIND)
+    d = capi.DeviceBuffer(data)
+    best = None
+    for _ in range(4):
+        try:
+            p.parse_device(d.ptr, d.n).free()
+        except capi.MdcError as e:
+            print("  (parse error expected in ablation:", e.code, ")")
+        t = p.timing()
+        best = (t.count_ms, t.write_ms) if best is None else (min(best[0], t.count_ms), min(best[1], t.write_ms))
+    print(f"  skip={os.environ.get('MDC_DEBUG_SKIP', '0')}: count {best[0]:.3f} ms  write {best[1]:.3f} ms")
+else:
+    for skip in ("0", "1", "2", "3"):
+        env = dict(os.environ, MDC_DEBUG_SKIP=skip)
+        subprocess.run([sys.executable, __file__, "child"], env=env, check=False)
