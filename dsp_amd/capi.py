@@ -30,7 +30,6 @@ MDC_ERR_NUMERIC = -7
 MDC_ERR_IO = -8
 MDC_ERR_INTERNAL = -9
 MDC_F_NO_RECOFF = 1
-MDC_F_TWO_PASS = 2
 
 # every symbol include/mdc_parse.h declares
 EXPORTS = [
@@ -73,7 +72,6 @@ class CTiming(ctypes.Structure):
         ("bytes_out", ctypes.c_uint64),
         ("rows", ctypes.c_int64),
         ("tiles", ctypes.c_int),
-        ("passes", ctypes.c_int),
     ]
 
 

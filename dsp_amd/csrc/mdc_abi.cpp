@@ -20,7 +20,7 @@
 #include "mdc_parse.h"
 
 namespace mdc {
-hipError_t launch_tile_kernel(int mode, const TileParams &P, uint32_t grid, hipStream_t stream);
+hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t stream);
 hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt,
                              hipStream_t stream);
 hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_t *const *bytes,
@@ -59,7 +59,6 @@ static int fail(int code, const char *fmt, ...) {
 
 struct Device {
     int id = -1;
-    int cus = 256;
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::multimap<size_t, void *> free_blocks;
@@ -87,7 +86,6 @@ static int get_device(int id, Device **out) {
     Device *d = new Device();
     d->id = id;
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-    HIP_TRY(hipDeviceGetAttribute(&d->cus, hipDeviceAttributeMultiprocessorCount, id));
     g_devices[id] = d;
     *out = d;
     return MDC_OK;
@@ -161,15 +159,6 @@ struct mdc_parser {
     uint32_t *d_status = nullptr;
     size_t ws_tiles = 0;
     uint64_t *h_totals = nullptr;  // pinned: ncols+1 totals + status
-    uint64_t *h_cap = nullptr;     // pinned: ncols+1 capacities
-    void **h_ptrs = nullptr;       // pinned: 3*ncols column pointers
-    uint64_t *d_cap = nullptr;
-    // single pass
-    uint32_t *d_lb_flags = nullptr;
-    uint64_t *d_lb_agg = nullptr, *d_lb_incl = nullptr;
-    size_t lb_tiles = 0;
-    std::vector<double> est;       // output bytes per input byte of every column, then rows per byte
-    bool est_valid = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     mdc_timing timing{};
 };
@@ -226,8 +215,6 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         o += round16(2 * (ncols + 1) * 4);
         L.dbm = o;
         o += round16((LB_FIRST / 64 + BLOCK + 1) * 8);
-        L.basepref = o;
-        o += round16((ncols + 1) * 8);
         L.schema = o;
         o += round16(blob_bytes);
         L.misc = o;
@@ -410,13 +397,6 @@ static int parser_finish(mdc_parser *p, const mdc_opts *opts) {
     p->d_status = (uint32_t *)st;
     HIP_TRY(hipMemset(p->d_status, 0, 256));
     HIP_TRY(hipHostMalloc((void **)&p->h_totals, (MAX_COLS + 8) * sizeof(uint64_t), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **)&p->h_cap, (MAX_COLS + 8) * sizeof(uint64_t), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **)&p->h_ptrs, 3 * MAX_COLS * sizeof(void *), hipHostMallocDefault));
-    void *dc = nullptr;
-    rc = dev_alloc(p->dev, (MAX_COLS + 8) * 8, &dc);
-    if (rc) return rc;
-    p->d_cap = (uint64_t *)dc;
-    p->est.assign((size_t)p->ncols + 1, 0.0);
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&p->ev[i]));
     return MDC_OK;
 }
@@ -486,12 +466,6 @@ extern "C" void mdc_parser_destroy(mdc_parser *p) {
         dev_free(p->dev, p->d_base);
         dev_free(p->dev, p->d_status);
         if (p->h_totals) (void)hipHostFree(p->h_totals);
-        if (p->h_cap) (void)hipHostFree(p->h_cap);
-        if (p->h_ptrs) (void)hipHostFree(p->h_ptrs);
-        dev_free(p->dev, p->d_cap);
-        dev_free(p->dev, p->d_lb_flags);
-        dev_free(p->dev, p->d_lb_agg);
-        dev_free(p->dev, p->d_lb_incl);
         for (int i = 0; i < 4; ++i)
             if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
     }
@@ -546,217 +520,6 @@ static int status_to_error(uint32_t st) {
     return MDC_OK;
 }
 
-// Allocates every device buffer of a batch for `rows` rows and cap[c] cell bytes per column,
-// and uploads the arrays of column pointers the kernels index.
-static int alloc_batch(mdc_parser *p, uint64_t rows, const uint64_t *cap, mdc_batch **out) {
-    Device *d = p->dev;
-    const uint32_t ncols = (uint32_t)p->ncols;
-    mdc_batch *b = new mdc_batch();
-    b->dev = d;
-    b->rows = (int64_t)rows;
-    b->ncols = (int)ncols;
-    b->words = p->words;
-    b->typed = p->typed;
-    for (auto &c : p->cols) b->collen.push_back(c.collen);
-    b->d_off.assign(ncols, nullptr);
-    b->d_bytes.assign(ncols, nullptr);
-    b->d_val.assign(ncols, nullptr);
-    b->nbytes.assign(ncols, 0);
-    b->h_off.resize(ncols);
-    b->h_bytes.resize(ncols);
-    b->h_val.resize(ncols);
-    b->have_col.assign(ncols, false);
-    b->have_val.assign(ncols, false);
-    b->h_fixed.resize(ncols);
-    b->fixed_stride.assign(ncols, 0);
-    int rc = MDC_OK;
-    void *q = nullptr;
-#define ALLOC_OR_FAIL(bytes, dst, T)     \
-    do {                                 \
-        rc = dev_alloc(d, (bytes), &q);  \
-        if (rc) {                        \
-            batch_release(b);            \
-            return rc;                   \
-        }                                \
-        dst = (T)q;                      \
-    } while (0)
-    if (!(p->flags & MDC_F_NO_RECOFF)) ALLOC_OR_FAIL((rows + 1) * 8, b->d_rec_off, uint64_t *);
-    for (uint32_t c = 0; c < ncols; ++c) {
-        b->nbytes[c] = cap[c];
-        ALLOC_OR_FAIL((rows + 1) * 4, b->d_off[c], uint32_t *);
-        ALLOC_OR_FAIL(cap[c] + 16, b->d_bytes[c], uint8_t *);
-        if (p->typed[c] != MDC_T_NONE) ALLOC_OR_FAIL(rows * 8 + 8, b->d_val[c], uint64_t *);
-    }
-    ALLOC_OR_FAIL(rows * p->words * 4 + 4, b->d_valid, uint32_t *);
-    ALLOC_OR_FAIL(rows * p->words * 4 + 4, b->d_found, uint32_t *);
-    ALLOC_OR_FAIL(3 * (size_t)ncols * sizeof(void *), b->d_ptrs, void *);
-#undef ALLOC_OR_FAIL
-    void **hp = p->h_ptrs;  // pinned
-    for (uint32_t c = 0; c < ncols; ++c) {
-        hp[c] = b->d_off[c];
-        hp[ncols + c] = b->d_bytes[c];
-        hp[2 * ncols + c] = b->d_val[c];
-    }
-    hipError_t e = hipMemcpyAsync(b->d_ptrs, hp, 3 * (size_t)ncols * sizeof(void *), hipMemcpyHostToDevice, d->stream);
-    if (e != hipSuccess) {
-        batch_release(b);
-        return fail(MDC_ERR_HIP, "pointer upload: %s", hipGetErrorString(e));
-    }
-    *out = b;
-    return MDC_OK;
-}
-
-static uint64_t algorithmic_out_bytes(const mdc_parser *p, uint64_t rows, const uint64_t *totals) {
-    uint64_t o = (p->flags & MDC_F_NO_RECOFF) ? 0 : (rows + 1) * 8;
-    for (int c = 0; c < p->ncols; ++c) {
-        o += (rows + 1) * 4 + totals[c];
-        if (p->typed[c] != MDC_T_NONE) o += rows * 8;
-    }
-    return o + 2 * rows * p->words * 4;
-}
-
-static void set_out_params(TileParams &P, mdc_batch *b, uint32_t ncols) {
-    P.rec_off = b->d_rec_off;
-    P.off = (uint32_t *const *)b->d_ptrs;
-    P.bytes = (uint8_t *const *)((void **)b->d_ptrs + ncols);
-    P.val = (uint64_t *const *)((void **)b->d_ptrs + 2 * ncols);
-    P.valid = b->d_valid;
-    P.found = b->d_found;
-}
-
-// second stage of the typed conversion, when the tile kernel deferred some cells
-static int run_deferred(mdc_parser *p, mdc_batch *b, const TileParams &P, uint64_t rows) {
-    hipStream_t s = p->dev->stream;
-    hipError_t le = launch_long_float((const uint8_t *)p->d_blob, P.off, P.bytes, P.val, b->d_valid, b->d_found, rows,
-                                      (uint32_t)p->ncols, s);
-    if (le == hipSuccess) le = hipStreamSynchronize(s);
-    if (le != hipSuccess) return fail(MDC_ERR_HIP, "deferred conversion: %s", hipGetErrorString(le));
-    return MDC_OK;
-}
-
-static int ensure_lookback_workspace(mdc_parser *p, size_t ntiles) {
-    if (ntiles <= p->lb_tiles && p->d_lb_flags) return MDC_OK;
-    dev_free(p->dev, p->d_lb_flags);
-    dev_free(p->dev, p->d_lb_agg);
-    dev_free(p->dev, p->d_lb_incl);
-    p->d_lb_flags = nullptr;
-    p->d_lb_agg = p->d_lb_incl = nullptr;
-    p->lb_tiles = 0;
-    const size_t ncnt = (size_t)p->ncols + 1;
-    void *a = nullptr, *b = nullptr, *c = nullptr;
-    int rc = dev_alloc(p->dev, (ntiles + 4) * 4, &a);  // flags, then the ticket counter
-    if (!rc) rc = dev_alloc(p->dev, ntiles * ncnt * 8, &b);
-    if (!rc) rc = dev_alloc(p->dev, ntiles * ncnt * 8, &c);
-    if (rc) {
-        dev_free(p->dev, a);
-        dev_free(p->dev, b);
-        dev_free(p->dev, c);
-        return rc;
-    }
-    p->d_lb_flags = (uint32_t *)a;
-    p->d_lb_agg = (uint64_t *)b;
-    p->d_lb_incl = (uint64_t *)c;
-    p->lb_tiles = ntiles;
-    return MDC_OK;
-}
-
-enum { SP_FALLBACK = 1000 };  // internal: take the two-pass form instead
-
-// Single pass: one persistent kernel reads the input once.  The output buffers are sized from
-// the previous parse of this parser (bytes per input byte of every column); a tile that does
-// not fit is refused by the kernel and the parse is repeated with the exact sizes, which the
-// look-back chain has produced anyway.
-static int parse_single(mdc_parser *p, TileParams P, size_t n, mdc_batch **out) {
-    Device *d = p->dev;
-    hipStream_t s = d->stream;
-    const uint32_t ncols = (uint32_t)p->ncols, ncnt = ncols + 1;
-    const size_t ntiles = P.ntiles;
-    int rc = ensure_lookback_workspace(p, ntiles);
-    if (rc) return rc;
-    uint64_t *cap = p->h_cap;  // pinned, ncnt entries
-    for (uint32_t c = 0; c < ncols; ++c) cap[c] = (uint64_t)(p->est[c] * (double)n * 1.03) + 65536;
-    cap[ncols] = (uint64_t)(p->est[ncols] * (double)n * 1.03) + 1024;
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        for (uint32_t c = 0; c < ncols; ++c)
-            if (cap[c] > 0xFFFFFFFFull) return fail(MDC_ERR_TOO_LARGE, "column %u holds more than 4 GiB; split the input", c);
-        mdc_batch *b = nullptr;
-        rc = alloc_batch(p, cap[ncols], cap, &b);
-        if (rc) return rc;
-        P.L = p->Ls[p->lb_level];
-        set_out_params(P, b, ncols);
-        P.lb_flags = p->d_lb_flags;
-        P.ticket = p->d_lb_flags + ntiles;
-        P.lb_agg = p->d_lb_agg;
-        P.lb_incl = p->d_lb_incl;
-        P.cap = p->d_cap;
-        hipError_t e = hipMemcpyAsync(p->d_cap, cap, ncnt * 8, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemsetAsync(p->d_lb_flags, 0, (ntiles + 4) * 4, s);
-        if (e == hipSuccess) e = hipMemsetAsync(p->d_status, 0, 4, s);
-        if (e == hipSuccess) e = hipEventRecord(p->ev[0], s);
-        uint32_t per_cu = 160 * 1024 / P.L.total;
-        if (per_cu > 4) per_cu = 4;
-        if (per_cu < 1) per_cu = 1;
-        if (e == hipSuccess) e = launch_tile_kernel(2, P, (uint32_t)d->cus * per_cu, s);
-        if (e == hipSuccess) e = hipEventRecord(p->ev[3], s);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(p->h_totals, p->d_lb_incl + (ntiles - 1) * ncnt, ncnt * 8, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(p->h_totals + ncnt, p->d_status, 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) {
-            batch_release(b);
-            return fail(MDC_ERR_HIP, "single pass: %s", hipGetErrorString(e));
-        }
-        const uint32_t st = (uint32_t)p->h_totals[ncnt];
-        if (st & ST_TIMEOUT) {  // never expected; the two-pass form has no inter-block dependency
-            batch_release(b);
-            p->est_valid = false;
-            return SP_FALLBACK;
-        }
-        if (st & ST_RECORD_TOO_LONG) {
-            batch_release(b);
-            if (p->lb_level < 2) {
-                ++p->lb_level;
-                continue;
-            }
-            return status_to_error(ST_RECORD_TOO_LONG);
-        }
-        const uint64_t rows = p->h_totals[ncols];
-        for (uint32_t c = 0; c < ncnt; ++c) p->est[c] = n ? (double)p->h_totals[c] / (double)n : 0.0;
-        if (st & ST_OVERFLOW) {  // exact sizes are known now
-            batch_release(b);
-            for (uint32_t c = 0; c < ncnt; ++c) cap[c] = p->h_totals[c];
-            continue;
-        }
-        b->rows = (int64_t)rows;
-        for (uint32_t c = 0; c < ncols; ++c) b->nbytes[c] = p->h_totals[c];
-        if (st & ST_NUMERIC_RANGE) {
-            rc = run_deferred(p, b, P, rows);
-            if (rc) {
-                batch_release(b);
-                return rc;
-            }
-        }
-        rc = status_to_error(st & ~(ST_NUMERIC_RANGE));
-        if (rc) {
-            batch_release(b);
-            return rc;
-        }
-        mdc_timing &t = p->timing;
-        t.count_ms = 0;
-        t.scan_ms = 0;
-        (void)hipEventElapsedTime(&t.write_ms, p->ev[0], p->ev[3]);
-        t.total_ms = t.write_ms;
-        t.bytes_in = n;
-        t.bytes_out = algorithmic_out_bytes(p, rows, p->h_totals);
-        t.rows = (int64_t)rows;
-        t.tiles = (int)ntiles;
-        t.passes = 1;
-        *out = b;
-        return MDC_OK;
-    }
-    return fail(MDC_ERR_INTERNAL, "single pass did not converge");
-}
-
 extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc_batch **out) {
     if (!p || !out) return fail(MDC_ERR_ARG, "NULL argument");
     *out = nullptr;
@@ -783,11 +546,6 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     if (const char *dbg = getenv("MDC_DEBUG_SKIP")) P.debug = (uint32_t)atoi(dbg);
 #endif
 
-    if (p->est_valid && ntiles > 0 && !(p->flags & MDC_F_TWO_PASS)) {
-        rc = parse_single(p, P, n, out);
-        if (rc != SP_FALLBACK) return rc;
-    }
-
     hipStream_t s = d->stream;
     // Sizing pass.  The look-behind capacity starts at the level that fitted the previous
     // parse; a record that does not fit raises ST_RECORD_TOO_LONG and the pass is repeated
@@ -796,7 +554,7 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
         P.L = p->Ls[p->lb_level];
         HIP_TRY(hipMemsetAsync(p->d_status, 0, 4, s));
         HIP_TRY(hipEventRecord(p->ev[0], s));
-        HIP_TRY(launch_tile_kernel(0, P, 0, s));
+        HIP_TRY(launch_tile_kernel(false, P, s));
         HIP_TRY(hipEventRecord(p->ev[1], s));
         HIP_TRY(launch_scan_tiles(p->d_counts, p->d_base, (uint32_t)ntiles, ncnt, s));
         HIP_TRY(hipEventRecord(p->ev[2], s));
@@ -819,22 +577,78 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
         if (p->h_totals[c] > 0xFFFFFFFFull)
             return fail(MDC_ERR_TOO_LARGE, "column %u holds %llu bytes; split the input", c,
                         (unsigned long long)p->h_totals[c]);
-    // remember the shape of this input: the next parse can size its buffers from it
-    for (uint32_t c = 0; c < ncnt; ++c) p->est[c] = n ? (double)p->h_totals[c] / (double)n : 0.0;
-    p->est_valid = n > 0;
-    std::vector<uint64_t> totals(p->h_totals, p->h_totals + ncnt);
 
-    mdc_batch *b = nullptr;
-    rc = alloc_batch(p, rows, totals.data(), &b);
-    if (rc) return rc;
+    mdc_batch *b = new mdc_batch();
+    b->dev = d;
+    b->rows = (int64_t)rows;
+    b->ncols = (int)ncols;
+    b->words = p->words;
+    b->typed = p->typed;
+    for (auto &c : p->cols) b->collen.push_back(c.collen);
+    b->d_off.assign(ncols, nullptr);
+    b->d_bytes.assign(ncols, nullptr);
+    b->d_val.assign(ncols, nullptr);
+    b->nbytes.assign(ncols, 0);
+    b->h_off.resize(ncols);
+    b->h_bytes.resize(ncols);
+    b->h_val.resize(ncols);
+    b->have_col.assign(ncols, false);
+    b->have_val.assign(ncols, false);
+    b->h_fixed.resize(ncols);
+    b->fixed_stride.assign(ncols, 0);
+    uint64_t bytes_out = 0;
+    auto A = [&](size_t bytes, void **q) { return dev_alloc(d, bytes, q); };
+    void *q = nullptr;
+#define ALLOC_OR_FAIL(bytes, dst, T)     \
+    do {                                 \
+        rc = A((bytes), &q);             \
+        if (rc) {                        \
+            batch_release(b);            \
+            return rc;                   \
+        }                                \
+        dst = (T)q;                      \
+    } while (0)
+    if (!(p->flags & MDC_F_NO_RECOFF)) {
+        ALLOC_OR_FAIL((rows + 1) * 8, b->d_rec_off, uint64_t *);
+        bytes_out += (rows + 1) * 8;
+    }
+    for (uint32_t c = 0; c < ncols; ++c) {
+        b->nbytes[c] = p->h_totals[c];
+        ALLOC_OR_FAIL((rows + 1) * 4, b->d_off[c], uint32_t *);
+        ALLOC_OR_FAIL(b->nbytes[c] + 16, b->d_bytes[c], uint8_t *);
+        bytes_out += (rows + 1) * 4 + b->nbytes[c];
+        if (p->typed[c] != MDC_T_NONE) {
+            ALLOC_OR_FAIL(rows * 8 + 8, b->d_val[c], uint64_t *);
+            bytes_out += rows * 8;
+        }
+    }
+    ALLOC_OR_FAIL(rows * p->words * 4 + 4, b->d_valid, uint32_t *);
+    ALLOC_OR_FAIL(rows * p->words * 4 + 4, b->d_found, uint32_t *);
+    bytes_out += 2 * rows * p->words * 4;
+    ALLOC_OR_FAIL(3 * (size_t)ncols * sizeof(void *), b->d_ptrs, void *);
+    {
+        std::vector<void *> hp(3 * ncols);
+        for (uint32_t c = 0; c < ncols; ++c) {
+            hp[c] = b->d_off[c];
+            hp[ncols + c] = b->d_bytes[c];
+            hp[2 * ncols + c] = b->d_val[c];
+        }
+        HIP_TRY(hipMemcpyAsync(b->d_ptrs, hp.data(), hp.size() * sizeof(void *), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));  // hp is a stack object
+    }
     if (ntiles == 0) {
         // nothing to launch: every offset array is the single entry 0
         for (uint32_t c = 0; c < ncols; ++c) HIP_TRY(hipMemsetAsync(b->d_off[c], 0, 4, s));
         if (b->d_rec_off) HIP_TRY(hipMemsetAsync(b->d_rec_off, 0, 8, s));
     }
-    set_out_params(P, b, ncols);
+    P.rec_off = b->d_rec_off;
+    P.off = (uint32_t *const *)b->d_ptrs;
+    P.bytes = (uint8_t *const *)((void **)b->d_ptrs + ncols);
+    P.val = (uint64_t *const *)((void **)b->d_ptrs + 2 * ncols);
+    P.valid = b->d_valid;
+    P.found = b->d_found;
     HIP_TRY(hipEventRecord(p->ev[2], s));
-    hipError_t le = launch_tile_kernel(1, P, 0, s);
+    hipError_t le = launch_tile_kernel(true, P, s);
     if (le != hipSuccess) {
         batch_release(b);
         return fail(MDC_ERR_HIP, "launch: %s", hipGetErrorString(le));
@@ -848,10 +662,13 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     }
     uint32_t st = (uint32_t)p->h_totals[ncnt];
     if (st & ST_NUMERIC_RANGE) {
-        rc = run_deferred(p, b, P, rows);
-        if (rc) {
+        // some floating-point texts need the multi-precision stage
+        le = launch_long_float((const uint8_t *)p->d_blob, P.off, P.bytes, P.val, b->d_valid, b->d_found, rows, ncols,
+                               s);
+        if (le == hipSuccess) le = hipStreamSynchronize(s);
+        if (le != hipSuccess) {
             batch_release(b);
-            return rc;
+            return fail(MDC_ERR_HIP, "long_float: %s", hipGetErrorString(le));
         }
         st &= ~ST_NUMERIC_RANGE;
     }
@@ -863,10 +680,9 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     (void)hipEventElapsedTime(&t.write_ms, p->ev[2], p->ev[3]);
     (void)hipEventElapsedTime(&t.total_ms, p->ev[0], p->ev[3]);
     t.bytes_in = n;
-    t.bytes_out = algorithmic_out_bytes(p, rows, totals.data());
+    t.bytes_out = bytes_out;
     t.rows = (int64_t)rows;
     t.tiles = (int)ntiles;
-    t.passes = 2;
     *out = b;
     return MDC_OK;
 }

@@ -35,8 +35,6 @@ enum : uint32_t {
     ST_RECORD_TOO_LONG = 1u,
     ST_NUMERIC_RANGE = 2u,
     ST_INTERNAL = 4u,
-    ST_OVERFLOW = 8u,  // single pass: the estimated output buffers were too small
-    ST_TIMEOUT = 16u,  // single pass: a look-back never saw the tile in front of it
 };
 
 struct DevCol {
@@ -97,7 +95,6 @@ struct LdsLayout {
     uint32_t fmask;   // RB*words u32
     uint32_t coltot;  // 2*(ncols+1) u32: batch totals, tile totals
     uint32_t dbm;     // (LB_FIRST/64 + BLOCK + 1) u64: digit bitmap of the tile and the first look-behind window
-    uint32_t basepref;  // (ncols+1) u64: single pass, the tile's exclusive prefixes
     uint32_t schema;  // schema blob
     uint32_t misc;    // block-wide scalars
     uint32_t total;
@@ -125,12 +122,6 @@ struct TileParams {
     uint32_t *valid;             // rows*words
     uint32_t *found;             // rows*words
     uint32_t *status;
-    // single pass
-    uint32_t *ticket;            // next tile to hand out
-    uint32_t *lb_flags;          // [ntiles] 0 none, 1 totals published, 2 inclusive prefix published
-    uint64_t *lb_agg;            // [ntiles][ncols+1] totals of each tile
-    uint64_t *lb_incl;           // [ntiles][ncols+1] inclusive prefixes
-    const uint64_t *cap;         // [ncols+1] capacity of the output buffers (bytes per column, rows)
     uint32_t debug;  // diagnostic builds only: phases to skip (ablation timing)
 };
 

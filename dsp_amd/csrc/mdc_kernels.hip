@@ -26,8 +26,6 @@
 // deterministic) analysis and stores the columns.
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
-
 #include "mdc_device.h"
 #include "mdc_numparse.h"
 #include "mdc_bignum.h"
@@ -152,10 +150,6 @@ enum {
     MS_STAGED = 2,
     MS_LBCNT = 3,   // events found in the look-behind region
     MS_WTOT = 4,    // 4 words: per-wave totals of the rank/event scan
-    MS_SKIP = 8,    // single pass: the tile does not fit the output buffers
-    MS_TILE_WORDS = 9,   // words above are reset for every tile
-    MS_TICKET_NEXT = 10, // single pass: the block's next tile
-    MS_ABORT = 11,       // single pass: a look-back gave up
     MS_COUNT = 16
 };
 
@@ -577,14 +571,8 @@ __device__ __forceinline__ uint32_t desc_pack(uint32_t start, uint32_t len, uint
     return start | (len << 15) | (lvl << 30);
 }
 
-// MODE 0: sizing pass (per-tile byte and row counts).  MODE 1: write pass with tile bases from
-// the scan.  MODE 2: single pass: persistent blocks take tiles in ticket order, measure the
-// tile, obtain their bases from the preceding tiles through a decoupled look-back (chained
-// scan) and then write; the input is read once.
-template <int MODE>
+template <bool WRITE>
 __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
-    constexpr bool SINGLE = MODE == 2;
-    constexpr bool WRITE = MODE == 1;  // outputs of the two-pass form; the single pass decides per phase
     extern __shared__ __align__(16) uint8_t smem[];
     const LdsLayout &L = P.L;
     uint8_t *sdata = smem + L.data;
@@ -604,25 +592,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     STAMP_INIT;
 
     const int64_t n = (int64_t)P.n;
-    uint64_t *basepref = (uint64_t *)(smem + L.basepref);  // single pass: this tile's bases
-    {
-        const uint4 *g = (const uint4 *)P.schema;
-        uint4 *s = (uint4 *)(smem + L.schema);
-        for (uint32_t i = tid; i < P.schema_bytes / 16; i += BLOCK) s[i] = g[i];
-        if (tid < MS_COUNT && tid != MS_TICKET_NEXT) ms[tid] = 0;
-        if (SINGLE && tid == 0) ms[MS_TICKET_NEXT] = atomicAdd(P.ticket, 1u);
-    }
-    __syncthreads();
-    for (;;) {  // tiles of this block (one, unless persistent)
-    uint32_t tile;
-    if (SINGLE) {
-        tile = ms[MS_TICKET_NEXT];
-        if (tile >= P.ntiles || ms[MS_ABORT]) break;
-        __syncthreads();  // everybody has read the ticket before it is replaced
-    } else {
-        tile = blockIdx.x;
-    }
-    const int64_t tile_start = (int64_t)tile * TILE;
+    const int64_t tile_start = (int64_t)blockIdx.x * TILE;
     const int64_t tile_end = (tile_start + TILE < n) ? tile_start + TILE : n;
     const int LB = (int)L.lbmax;                // look-behind capacity of this launch
     const int64_t base_pos = tile_start - LB;  // global position of LDS index 0
@@ -654,8 +624,12 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         const int j = loaded_lo / CHUNK + tid;
         if (j < ts_li / CHUNK) ((uint4 *)sdata)[j] = load_chunk(j);
     }
-    if (tid < MS_TILE_WORDS) ms[tid] = tid == MS_LAST ? NONE : 0;
-    if (SINGLE && tid == 0) ms[MS_TICKET_NEXT] = atomicAdd(P.ticket, 1u);  // returns behind the tile loads
+    {
+        const uint4 *g = (const uint4 *)P.schema;
+        uint4 *s = (uint4 *)(smem + L.schema);
+        for (uint32_t i = tid; i < P.schema_bytes / 16; i += BLOCK) s[i] = g[i];
+        if (tid < MS_COUNT) ms[tid] = tid == MS_LAST ? NONE : 0;
+    }
     __syncthreads();
     const SchemaHdr *H = (const SchemaHdr *)(smem + L.schema);
     const DevCol *cols = (const DevCol *)(H + 1);
@@ -772,109 +746,20 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     }
     const bool has_nul = ms[MS_HASNUL] != 0;
     const uint32_t RB = L.RB, EVCAP = L.evcap;
-    const uint64_t *tb = WRITE ? P.tile_base + (uint64_t)tile * (ncols + 1) : SINGLE ? basepref : nullptr;
-    uint64_t row0 = WRITE ? tb[ncols] : 0;
-    if ((WRITE || SINGLE) && tile == 0) {
+    const uint64_t *tb = WRITE ? P.tile_base + (uint64_t)blockIdx.x * (ncols + 1) : nullptr;
+    const uint64_t row0 = WRITE ? tb[ncols] : 0;
+    if (WRITE && blockIdx.x == 0) {
         if (tid == 0 && P.rec_off) P.rec_off[0] = 0;
         for (uint32_t c = tid; c < ncols; c += BLOCK) P.off[c][0] = 0;
     }
+    if (tid == 0) recend[0] = (uint32_t)(s0_li - 1);
     const uint32_t seplen = H->sep_len;
     const int jlb0 = s0_li / CHUNK, jlb1 = ts_li / CHUNK;  // look-behind chunks of the first record
     STAMP(1);  // classify + rank scan
 
-    // ---- phases: the two-pass kernels run one (sizing or writing); the single pass measures,
-    // looks back for its bases, then writes
-    for (int ph = 0; ph < (SINGLE ? 2 : 1); ++ph) {
-    const bool emit = SINGLE ? ph == 1 : WRITE;
-    if (SINGLE && ph == 1) {
-        // ---- decoupled look-back: publish this tile's totals, sum the totals of the tiles in
-        // front of it until one that already knows its inclusive prefix
-        __syncthreads();
-        if (wave == 0) {
-            const uint32_t ncnt = ncols + 1;
-            const uint64_t mine = (uint32_t)lane < ncols ? tiletot[lane] : nrec;
-            uint64_t excl = 0;
-            bool failed = false;
-            if (tile == 0) {
-                if ((uint32_t)lane < ncnt)
-                    __hip_atomic_store(&P.lb_incl[(uint64_t)tile * ncnt + lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(&P.lb_flags[tile], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                if ((uint32_t)lane < ncnt)
-                    __hip_atomic_store(&P.lb_agg[(uint64_t)tile * ncnt + lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(&P.lb_flags[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint64_t *M = (uint64_t *)(smem + L.evlist);  // window x counters, in the idle event-list space
-                uint32_t WL = L.stage_cap / (8 * ncnt);
-                if (WL > 64) WL = 64;
-                int64_t pos = (int64_t)tile - 1;
-                uint32_t spins = 0;
-                for (;;) {
-                    const int64_t idx = pos - lane;
-                    uint32_t f = 3;  // lanes outside the window
-                    if ((uint32_t)lane < WL)
-                        f = idx >= 0 ? __hip_atomic_load(&P.lb_flags[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 2u;
-                    const uint64_t bi = __ballot(f == 2);
-                    const uint32_t fi = bi ? (uint32_t)__builtin_ctzll(bi) : WL;  // nearest inclusive prefix
-                    const uint64_t need = fi >= 64 ? ~0ull : ((2ull << fi) - 1);
-                    if (__ballot(f == 0) & need) {  // a tile in front has not published yet
-                        __builtin_amdgcn_s_sleep(8);
-                        if (++spins > (1u << 22) ||
-                            ((spins & 1023) == 0 &&
-                             (__hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_TIMEOUT))) {
-                            failed = true;
-                            break;
-                        }
-                        continue;
-                    }
-                    if ((uint32_t)lane <= fi && (uint32_t)lane < WL) {
-                        const uint64_t *src = ((uint32_t)lane < fi ? P.lb_agg : P.lb_incl) + (idx >= 0 ? idx : 0) * ncnt;
-                        for (uint32_t j = 0; j < ncnt; ++j)
-                            M[lane * ncnt + j] =
-                                idx >= 0 ? __hip_atomic_load(&src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-                    }
-                    const uint32_t nl = fi < WL ? fi + 1 : WL;
-                    if ((uint32_t)lane < ncnt)
-                        for (uint32_t l = 0; l < nl; ++l) excl += M[l * ncnt + lane];
-                    if (fi < WL) break;
-                    pos -= WL;
-                }
-                if (!failed) {
-                    if ((uint32_t)lane < ncnt)
-                        __hip_atomic_store(&P.lb_incl[(uint64_t)tile * ncnt + lane], excl + mine, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(&P.lb_flags[tile], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            if ((uint32_t)lane < ncnt) basepref[lane] = excl;
-            // capacity of the output buffers (sized from an estimate): refuse the tile, keep the chain
-            const bool over = (uint32_t)lane < ncnt && excl + mine > P.cap[lane];
-            if (__ballot(over)) {
-                if (lane == 0) {
-                    ms[MS_SKIP] = 1;
-                    atomicOr(P.status, ST_OVERFLOW);
-                }
-            }
-            if (failed && lane == 0) {
-                ms[MS_ABORT] = 1;
-                atomicOr(P.status, ST_TIMEOUT);
-            }
-        }
-        __syncthreads();
-        if (ms[MS_ABORT] || ms[MS_SKIP]) break;  // (uniform) nothing of this tile is written
-        row0 = basepref[ncols];
-        for (uint32_t c = tid; c < ncols + 1; c += BLOCK) tiletot[c] = 0;  // running offsets of the write phase
-        __syncthreads();
-    }
-    if (tid == 0) recend[0] = (uint32_t)(s0_li - 1);
     // ---- batches of RB records
     for (uint32_t rb0 = 0; rb0 < nrec; rb0 += RB) {
         const uint32_t RBn = (nrec - rb0 < RB) ? nrec - rb0 : RB;
-        // a tile of one batch keeps its tag positions from the measuring phase
-        const bool reuse = SINGLE && ph == 1 && nrec <= RB;
-        if (!reuse) {
         for (uint32_t i = tid; i < RB * npat; i += BLOCK) evt[i] = NONE;
         for (uint32_t i = tid; i < RB * W; i += BLOCK) {
             vmask[i] = 0;
@@ -891,11 +776,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 ++r;
             }
         }
-        }
         __syncthreads();
         STAMP(2);  // clears
 
-        if (!csv && !SKIP(1) && !reuse) {
+        if (!csv && !SKIP(1)) {
             // ---- C. the first record's events in the look-behind region (first batch only)
             if (rb0 == 0) {
                 for (int j = jlb0 + tid; j < jlb1; j += BLOCK) {
@@ -937,7 +821,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         STAMP(3);  // events
 
         // ---- E. cells: descriptor, length, typed value
-        if (csv && !reuse) {
+        if (csv) {
             // greedy left-to-right separator search, one lane per record (ccmdstr::splittocmd)
             if ((uint32_t)tid < RBn) {
                 const uint32_t r = tid;
@@ -1009,12 +893,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         bool deferred = false;
         uint8_t *const wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
         const uint32_t wstage_cap = L.stage_cap / (BLOCK / 64);
-        auto cells = [&](auto emit_tag) {
-        constexpr bool EMIT = decltype(emit_tag)::value;
         for (uint32_t c = wave; c < ncols && !SKIP(2); c += BLOCK / 64) {
             const uint32_t typed = cols[c].typed;
             const uint32_t clvl = cols[c].level;
-            uint64_t *const valp = (EMIT && typed != T_NONE) ? P.val[c] : nullptr;
+            uint64_t *const valp = (WRITE && typed != T_NONE) ? P.val[c] : nullptr;
             uint32_t cs_[RB_PASSES], cl_[RB_PASSES], cv_[RB_PASSES], cf_[RB_PASSES], cx_[RB_PASSES];
             uint64_t clo_[RB_PASSES], chi_[RB_PASSES];  // fast cells: their bytes, ready to store
             bool cfast_[RB_PASSES];
@@ -1070,7 +952,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                         if (found) atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
                     }
                     const bool convert = typed != T_NONE && (found || nulcut);
-                    const uint32_t ty = (EMIT && convert) ? typed : (uint32_t)T_NONE;  // sizing needs lengths only
+                    const uint32_t ty = (WRITE && convert) ? typed : (uint32_t)T_NONE;  // sizing needs lengths only
                     uint64_t value = 0;
                     bool valid = false;
                     if (len <= 16 && (int)s >= bm_lo) {
@@ -1100,7 +982,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                         flen = cell_filter_long<false>(sdata + s, len, lvl, nulcut, nullptr);
                         if (ty != T_NONE) deferred = true;  // value and valid bit come from the second stage
                     }
-                    if (EMIT && convert && valid) atomicOr(&vmask[r * W + (c >> 5)], 1u << (c & 31));
+                    if (WRITE && convert && valid) atomicOr(&vmask[r * W + (c >> 5)], 1u << (c & 31));
                     if (valp) valp[row0 + rb0 + r] = value;
                 }
                 const uint32_t incl = wave_incl_scan(flen);
@@ -1114,7 +996,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 cx_[ps] = total + incl - flen;
                 total += __shfl(incl, 63, 64);
             }
-            if (EMIT) {
+            if (WRITE) {
                 const uint64_t gb = tb[c] + tiletot[c];
                 const uint32_t a = (uint32_t)(gb & 15);
                 const bool staged = a + total <= wstage_cap;
@@ -1158,15 +1040,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             }
             if (lane == 0) tiletot[c] += total;  // this wave owns column c
         }
-        };
-        if (emit)
-            cells(std::true_type{});
-        else
-            cells(std::false_type{});
-        if (emit && deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
+        if (WRITE && deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
         __syncthreads();
         STAMP(5);  // cells: descriptors, lengths, values, staging, copy-out
-        if (emit && (uint32_t)tid < RBn) {
+        if (WRITE && (uint32_t)tid < RBn) {
             const uint64_t row = row0 + rb0 + tid;
             if (P.rec_off) P.rec_off[row + 1] = (uint64_t)(base_pos + (int64_t)recend[tid + 1] + 1);
             for (uint32_t w = 0; w < W; ++w) {
@@ -1178,17 +1055,13 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         STAMP(9);  // row outputs
         if (tid == 0) recend[0] = recend[RBn];
         __syncthreads();
-    }  // batches
-    }  // phases
+    }
 
-    if (MODE == 0) {
-        uint32_t *tc = P.tile_counts + (uint64_t)tile * (ncols + 1);
+    if (!WRITE) {
+        uint32_t *tc = P.tile_counts + (uint64_t)blockIdx.x * (ncols + 1);
         for (uint32_t c = tid; c < ncols; c += BLOCK) tc[c] = tiletot[c];
         if (tid == 0) tc[ncols] = nrec;
     }
-    if (!SINGLE) break;
-    __syncthreads();  // the LDS image is free for the next tile
-    }  // tiles
 }
 
 // Exclusive prefix over tiles of every counter (one block per counter).
@@ -1283,19 +1156,16 @@ hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_
     return hipGetLastError();
 }
 
-hipError_t launch_tile_kernel(int mode, const TileParams &P, uint32_t grid, hipStream_t stream) {
+hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t stream) {
     if (P.ntiles == 0) return hipSuccess;
     // per device and cheap: set on every launch so that each GPU of a process gets it
-    const void *fn = mode == 0 ? (const void *)tile_kernel<0> : mode == 1 ? (const void *)tile_kernel<1>
-                                                                        : (const void *)tile_kernel<2>;
+    const void *fn = write ? (const void *)tile_kernel<true> : (const void *)tile_kernel<false>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    if (mode == 0)
-        hipLaunchKernelGGL(tile_kernel<0>, dim3(P.ntiles), dim3(BLOCK), P.L.total, stream, P);
-    else if (mode == 1)
-        hipLaunchKernelGGL(tile_kernel<1>, dim3(P.ntiles), dim3(BLOCK), P.L.total, stream, P);
+    if (write)
+        hipLaunchKernelGGL(tile_kernel<true>, dim3(P.ntiles), dim3(BLOCK), P.L.total, stream, P);
     else
-        hipLaunchKernelGGL(tile_kernel<2>, dim3(grid < P.ntiles ? grid : P.ntiles), dim3(BLOCK), P.L.total, stream, P);
+        hipLaunchKernelGGL(tile_kernel<false>, dim3(P.ntiles), dim3(BLOCK), P.L.total, stream, P);
     return hipGetLastError();
 }
 

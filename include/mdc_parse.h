@@ -84,10 +84,7 @@ typedef struct mdc_opts {
 } mdc_opts;
 
 enum {
-    MDC_F_NO_RECOFF = 1u, /* do not materialise the record-offset array                     */
-    MDC_F_TWO_PASS = 2u   /* always size the outputs with a sizing pass (no inter-block      */
-                          /* dependency); default: a parser's first parse does, later ones   */
-                          /* run the single-pass kernel with buffers sized from that shape   */
+    MDC_F_NO_RECOFF = 1u  /* do not materialise the record-offset array                     */
 };
 
 typedef struct mdc_parser mdc_parser;
@@ -103,7 +100,6 @@ typedef struct mdc_timing {
     uint64_t bytes_out; /* algorithmic output bytes actually written  */
     int64_t rows;
     int tiles;
-    int passes;      /* 2 = sizing + write kernels, 1 = single-pass kernel (its time is write_ms) */
 } mdc_timing;
 
 /* ---- library ------------------------------------------------------------------------ */

@@ -15,15 +15,11 @@ ALL_T = list(range(1, 8))
 
 
 def _both_forms(p, data):
-    """A parser's first parse sizes its outputs with a sizing pass (two kernels); the next one
-    runs the single-pass kernel.  Both must give the same bytes."""
-    first = p.parse_host(data)
-    assert p.timing().passes == 2 or len(data) == 0
-    a = first.to_host()
-    second = p.parse_host(data)
-    assert p.timing().passes == (1 if len(data) else 2)
-    b = second.to_host()
-    assert_batches_equal(b, a, "single pass vs two pass")
+    """Parses twice with one parser: the second parse reuses the first one's device workspace
+    and must give the same bytes."""
+    a = p.parse_host(data).to_host()
+    b = p.parse_host(data).to_host()
+    assert_batches_equal(b, a, "second parse with the same parser")
     return b
 
 
@@ -238,38 +234,27 @@ def test_parse_file_and_accessors(tmp_path, port):
     p.close()
 
 
-def test_single_pass_resizes_when_the_shape_changes(port):
-    # the second input has far more bytes per column than the first: the single-pass kernel
-    # refuses the tiles that do not fit, the parse repeats with the exact sizes
+def test_workspace_follows_the_input_shape(port):
+    # one parser, inputs of very different size and bytes per column, in both directions
     small = b"<a>1</a><b>2</b><endl/>\n" * 4000
     big = b"".join(b"<a>abcde</a><b>%d.25</b><ab>%s</ab><endl/>\n" % (i, b"x" * (i % 200)) for i in range(6000))
     p = capi.Parser.xml(cases.SMALL)
     p.parse_host(small).free()
     got = p.parse_host(big).to_host()
-    assert p.timing().passes == 1
-    assert_batches_equal(got, port.parse_xml(big, cases.SMALL), "resized")
+    assert_batches_equal(got, port.parse_xml(big, cases.SMALL), "grown")
     got = p.parse_host(small).to_host()
     assert_batches_equal(got, port.parse_xml(small, cases.SMALL), "shrunk")
     p.close()
 
 
-def test_single_pass_many_tiles(port):
+def test_many_tiles(port):
     data, n = gen.mind_xml(nbytes=48 << 20)
     p = capi.Parser.xml(schema.ZHOBTMIND)
-    p.parse_host(data[: 1 << 20]).free()       # shape estimate from a small prefix
-    b = p.parse_host(data)
-    assert p.timing().passes == 1
-    got = b.to_host()
+    got = p.parse_host(data).to_host()
     exp = port.parse_xml(data, schema.ZHOBTMIND)
     assert got.rows == n
-    assert_batches_equal(got, exp, "single pass 48 MiB")
-    flags = capi.MDC_F_TWO_PASS
-    p2 = capi.Parser.xml(schema.ZHOBTMIND, flags=flags)
-    p2.parse_host(data[: 1 << 20]).free()
-    p2.parse_host(data).free()
-    assert p2.timing().passes == 2
+    assert_batches_equal(got, exp, "48 MiB")
     p.close()
-    p2.close()
 
 
 def test_device_resident_input(port):

@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if len(sys.argv) > 1 and sys.argv[1] == "child":
+if os.environ.get("MDC_ABLATE_CHILD"):
     sys.path.insert(0, ROOT)
     from dsp_amd import capi, gen, schema
     capi.LIB_PATH = os.path.join(ROOT, "dsp_amd", "libmdc_parse_ablate.so")
@@ -13,7 +13,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     p = capi.Parser.xml(schema.ZHOBTMIND)
     d = capi.DeviceBuffer(data)
     best = None
-    for _ in range(4):
+    for _ in range(6):
         try:
             p.parse_device(d.ptr, d.n).free()
         except capi.MdcError as e:
@@ -22,6 +22,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         best = (t.count_ms, t.write_ms) if best is None else (min(best[0], t.count_ms), min(best[1], t.write_ms))
     print(f"  skip={os.environ.get('MDC_DEBUG_SKIP', '0')}: count {best[0]:.3f} ms  write {best[1]:.3f} ms")
 else:
-    for skip in ("0", "1", "2", "3"):
-        env = dict(os.environ, MDC_DEBUG_SKIP=skip)
-        subprocess.run([sys.executable, __file__, "child"], env=env, check=False)
+    for skip in sys.argv[1:] or ("0", "1", "2", "3"):
+        env = dict(os.environ, MDC_DEBUG_SKIP=skip, MDC_ABLATE_CHILD="1")
+        subprocess.run([sys.executable, __file__], env=env, check=False)
