@@ -28,3 +28,28 @@ for p in sorted(glob.glob(os.path.join(out, "pmc*"))):
         print("  ", k)
         for c in sorted(agg[k]):
             print("      %-24s %16.1f" % (c, agg[k][c] / cnt[k][c]))
+
+# HBM traffic of the dominant kernel per launch: FETCH_SIZE and WRITE_SIZE count KB; on gfx950
+# FETCH_SIZE tallies the 128-byte read requests of wide streaming loads at 64 bytes, so it is
+# doubled.  Written as JSON so that bench.py can quote it next to the algorithmic bytes.
+import json
+
+def _avg(passdir, counter, kernel_sub):
+    files = glob.glob(os.path.join(out, passdir, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        return None
+    # one row per dispatch and counter instance: sum the instances of a dispatch, average the dispatches
+    per = defaultdict(float)
+    for row in csv.DictReader(open(files[0])):
+        if row["Counter_Name"] == counter and kernel_sub in row["Kernel_Name"]:
+            per[row["Dispatch_Id"]] += float(row["Counter_Value"])
+    return sum(per.values()) / len(per) if per else None
+
+kernel_sub = "tile_kernel<true>" if len(sys.argv) < 3 else sys.argv[2]
+f, w = _avg("pmc3", "FETCH_SIZE", kernel_sub), _avg("pmc4", "WRITE_SIZE", kernel_sub)
+if f is not None and w is not None:
+    t = {"kernel": kernel_sub, "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
+         "traffic_bytes": 2 * f * 1024 + w * 1024,
+         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; KB units; FETCH_SIZE doubled (gfx950)"}
+    json.dump(t, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    print("== traffic per launch:", json.dumps(t))
