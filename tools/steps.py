@@ -1,17 +1,29 @@
-"""Diagnostic: per-parse device timings of consecutive parses of one 1 GiB batch."""
+"""Diagnostic: per-parse timings of consecutive parses of one batch.
+usage: steps.py [xml|csv] [device|host] [bytes]"""
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dsp_amd import capi, gen, schema
 
-data, rows = gen.mind_xml(nbytes=int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 30)
-p = capi.Parser.xml(schema.ZHOBTMIND)
-d = capi.DeviceBuffer(data)
-for i in range(8):
-    b = p.parse_device(d.ptr, d.n)
+wl = sys.argv[1] if len(sys.argv) > 1 else "xml"
+src = sys.argv[2] if len(sys.argv) > 2 else "device"
+nbytes = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 30
+if wl == "xml":
+    data, rows = gen.mind_xml(nbytes=nbytes)
+    p = capi.Parser.xml(schema.ZHOBTMIND)
+else:
+    data, rows = gen.mind_csv(nbytes=nbytes)
+    p = capi.Parser.csv(",", 10, typed=schema.MIND_CSV_TYPED)
+d = capi.DeviceBuffer(data) if src == "device" else None
+for i in range(6):
+    t0 = time.perf_counter()
+    b = p.parse_device(d.ptr, d.n) if d else p.parse_host(data)
+    wall = time.perf_counter() - t0
     t = p.timing()
-    print(f"parse {i}: count {t.count_ms:.3f} scan {t.scan_ms:.3f} write {t.write_ms:.3f} "
-          f"total {t.total_ms:.3f} rows {t.rows}", flush=True)
+    print(f"{wl}/{src} parse {i}: count {t.count_ms:.3f} scan {t.scan_ms:.3f} write {t.write_ms:.3f} "
+          f"device total {t.total_ms:.3f} ms, wall {wall * 1e3:.3f} ms = {len(data) / wall / 1e9:.2f} GB/s, "
+          f"rows {t.rows}, out {t.bytes_out}", flush=True)
     b.free()
