@@ -2,6 +2,7 @@
 
     libmdc_parse.so   the product: gfx950 kernels + C ABI (hipcc)
     libmdc_gen.so     synthetic data generator (gcc)
+    examples/xmltodb_loop   the C++ ingest loop over include/mdc_xmltodb.hpp (g++)
 """
 from __future__ import annotations
 
@@ -39,7 +40,7 @@ def _run(cmd):
 def build_parse(force=False):
     target = os.path.join(HERE, "libmdc_parse.so")
     srcs = [os.path.join(CSRC, f) for f in ("mdc_kernels.hip", "mdc_abi.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("mdc_device.h", "mdc_numparse.h")] + \
+    deps = srcs + [os.path.join(CSRC, f) for f in ("mdc_device.h", "mdc_numparse.h", "mdc_bignum.h")] + \
         [os.path.join(ROOT, "include", "mdc_parse.h")]
     if force or _newer(target, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -67,8 +68,19 @@ def build_gen(force=False):
     return target
 
 
+def build_examples(force=False):
+    target = os.path.join(ROOT, "examples", "xmltodb_loop")
+    src = os.path.join(ROOT, "examples", "xmltodb_loop.cpp")
+    deps = [src, os.path.join(ROOT, "include", "mdc_xmltodb.hpp"), os.path.join(ROOT, "include", "mdc_parse.h"),
+            os.path.join(HERE, "libmdc_parse.so")]
+    if force or _newer(target, deps):
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), src, "-o", target,
+              "-L", HERE, "-lmdc_parse", "-Wl,-rpath,$ORIGIN/../dsp_amd"])
+    return target
+
+
 def build_all(force=False):
-    return [build_parse(force), build_gen(force)]
+    return [build_parse(force), build_gen(force), build_examples(force)]
 
 
 if __name__ == "__main__":
