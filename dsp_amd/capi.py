@@ -72,6 +72,7 @@ class CTiming(ctypes.Structure):
         ("bytes_out", ctypes.c_uint64),
         ("rows", ctypes.c_int64),
         ("tiles", ctypes.c_int),
+        ("full_write", ctypes.c_int),
     ]
 
 

@@ -21,6 +21,7 @@
 
 namespace mdc {
 hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t stream);
+hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream);
 hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt,
                              hipStream_t stream);
 hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_t *const *bytes,
@@ -157,6 +158,10 @@ struct mdc_parser {
     uint32_t *d_counts = nullptr;
     uint64_t *d_base = nullptr;
     uint32_t *d_status = nullptr;
+    uint32_t *d_hdr = nullptr;      // per tile: cell map slot, first record start
+    uint32_t *d_cellmap = nullptr;  // (ncols + 1) x map_cap words
+    size_t map_cap = 0;
+    double rows_per_byte = 0;       // of the previous parse; sizes the cell map
     size_t ws_tiles = 0;
     uint64_t *h_totals = nullptr;  // pinned: ncols+1 totals + status
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -465,6 +470,8 @@ extern "C" void mdc_parser_destroy(mdc_parser *p) {
         dev_free(p->dev, p->d_counts);
         dev_free(p->dev, p->d_base);
         dev_free(p->dev, p->d_status);
+        dev_free(p->dev, p->d_hdr);
+        dev_free(p->dev, p->d_cellmap);
         if (p->h_totals) (void)hipHostFree(p->h_totals);
         for (int i = 0; i < 4; ++i)
             if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
@@ -495,11 +502,17 @@ static int ensure_workspace(mdc_parser *p, size_t ntiles) {
     if (ntiles <= p->ws_tiles && p->d_counts) return MDC_OK;
     dev_free(p->dev, p->d_counts);
     dev_free(p->dev, p->d_base);
+    dev_free(p->dev, p->d_hdr);
     p->d_counts = nullptr;
     p->d_base = nullptr;
+    p->d_hdr = nullptr;
+    p->ws_tiles = 0;
     size_t ncnt = (size_t)p->ncols + 1;
-    void *a = nullptr, *b = nullptr;
-    int rc = dev_alloc(p->dev, ntiles * ncnt * 4, &a);
+    void *a = nullptr, *b = nullptr, *h = nullptr;
+    int rc = dev_alloc(p->dev, ntiles * 8 + 16, &h);
+    if (rc) return rc;
+    p->d_hdr = (uint32_t *)h;
+    rc = dev_alloc(p->dev, ntiles * ncnt * 4, &a);
     if (rc) return rc;
     rc = dev_alloc(p->dev, (ntiles + 1) * ncnt * 8, &b);
     if (rc) {
@@ -509,6 +522,26 @@ static int ensure_workspace(mdc_parser *p, size_t ntiles) {
     p->d_counts = (uint32_t *)a;
     p->d_base = (uint64_t *)b;
     p->ws_tiles = ntiles;
+    return MDC_OK;
+}
+
+// Room for the cell map: one word per column and record, plus the record ends.  The number of
+// records is not known before the sizing pass, so the capacity is a guess (the previous
+// parse's records per byte with a margin, else one record per 32 bytes); tiles that find no
+// room are written by the full write kernel instead.  The allocation counter sits behind it.
+static int ensure_cellmap(mdc_parser *p, size_t n) {
+    double rpb = p->rows_per_byte > 0 ? p->rows_per_byte * 1.125 : 1.0 / 32;
+    size_t want = (size_t)((double)n * rpb) + 4096;
+    if (want > 0xFFFF0000u) want = 0xFFFF0000u;
+    if (p->d_cellmap && want <= p->map_cap && p->map_cap <= 4 * want) return MDC_OK;
+    dev_free(p->dev, p->d_cellmap);
+    p->d_cellmap = nullptr;
+    p->map_cap = 0;
+    void *m = nullptr;
+    int rc = dev_alloc(p->dev, ((size_t)p->ncols + 1) * want * 4 + 64, &m);
+    if (rc) return rc;
+    p->d_cellmap = (uint32_t *)m;
+    p->map_cap = want;
     return MDC_OK;
 }
 
@@ -532,6 +565,8 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     const size_t ntiles = (n + TILE - 1) / TILE;
     int rc = ensure_workspace(p, ntiles ? ntiles : 1);
     if (rc) return rc;
+    rc = ensure_cellmap(p, n);
+    if (rc) return rc;
 
     TileParams P{};
     P.data = (const uint8_t *)d_data;
@@ -542,6 +577,10 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     P.tile_counts = p->d_counts;
     P.tile_base = p->d_base;
     P.status = p->d_status;
+    P.cellmap = p->d_cellmap;
+    P.map_cap = (uint32_t)p->map_cap;
+    P.map_alloc = p->d_cellmap + ((size_t)p->ncols + 1) * p->map_cap;
+    P.tile_hdr = p->d_hdr;
 #ifdef MDC_ABLATE
     if (const char *dbg = getenv("MDC_DEBUG_SKIP")) P.debug = (uint32_t)atoi(dbg);
 #endif
@@ -553,6 +592,7 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     for (;;) {
         P.L = p->Ls[p->lb_level];
         HIP_TRY(hipMemsetAsync(p->d_status, 0, 4, s));
+        HIP_TRY(hipMemsetAsync(P.map_alloc, 0, 4, s));
         HIP_TRY(hipEventRecord(p->ev[0], s));
         HIP_TRY(launch_tile_kernel(false, P, s));
         HIP_TRY(hipEventRecord(p->ev[1], s));
@@ -567,12 +607,14 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
         }
         break;
     }
-    rc = status_to_error((uint32_t)p->h_totals[ncnt] & ~ST_NUMERIC_RANGE);
+    const bool unmapped = ((uint32_t)p->h_totals[ncnt] & ST_UNMAPPED) != 0;
+    rc = status_to_error((uint32_t)p->h_totals[ncnt] & ~(ST_NUMERIC_RANGE | ST_UNMAPPED));
     if (rc) return rc;
     mdc_timing &t = p->timing;
     (void)hipEventElapsedTime(&t.count_ms, p->ev[0], p->ev[1]);
     (void)hipEventElapsedTime(&t.scan_ms, p->ev[1], p->ev[2]);
     const uint64_t rows = p->h_totals[ncols];
+    if (n) p->rows_per_byte = (double)rows / (double)n;
     for (uint32_t c = 0; c < ncols; ++c)
         if (p->h_totals[c] > 0xFFFFFFFFull)
             return fail(MDC_ERR_TOO_LARGE, "column %u holds %llu bytes; split the input", c,
@@ -648,7 +690,12 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     P.valid = b->d_valid;
     P.found = b->d_found;
     HIP_TRY(hipEventRecord(p->ev[2], s));
-    hipError_t le = launch_tile_kernel(true, P, s);
+    // tiles with a complete cell map take the short write kernel, the others the full one
+    hipError_t le = launch_emit_kernel(P, s);
+    if (le == hipSuccess && unmapped) {
+        P.only_unmapped = 1;
+        le = launch_tile_kernel(true, P, s);
+    }
     if (le != hipSuccess) {
         batch_release(b);
         return fail(MDC_ERR_HIP, "launch: %s", hipGetErrorString(le));
@@ -660,7 +707,7 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
         batch_release(b);
         return fail(MDC_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(se));
     }
-    uint32_t st = (uint32_t)p->h_totals[ncnt];
+    uint32_t st = (uint32_t)p->h_totals[ncnt] & ~ST_UNMAPPED;
     if (st & ST_NUMERIC_RANGE) {
         // some floating-point texts need the multi-precision stage
         le = launch_long_float((const uint8_t *)p->d_blob, P.off, P.bytes, P.val, b->d_valid, b->d_found, rows, ncols,
@@ -683,6 +730,7 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     t.bytes_out = bytes_out;
     t.rows = (int64_t)rows;
     t.tiles = (int)ntiles;
+    t.full_write = unmapped ? 1 : 0;
     *out = b;
     return MDC_OK;
 }

@@ -35,6 +35,7 @@ enum : uint32_t {
     ST_RECORD_TOO_LONG = 1u,
     ST_NUMERIC_RANGE = 2u,
     ST_INTERNAL = 4u,
+    ST_UNMAPPED = 8u,  // a tile of the sizing pass left no cell map: the write pass re-derives it
 };
 
 struct DevCol {
@@ -122,6 +123,15 @@ struct TileParams {
     uint32_t *valid;             // rows*words
     uint32_t *found;             // rows*words
     uint32_t *status;
+    // cell map: the sizing pass leaves, for every record of a tile, one word per column (source
+    // start | length | filter level | found) and the record's end, so that the write pass needs
+    // neither the tag search nor the record split again.  Column-major: word (c, slot + r) at
+    // cellmap[c * map_cap + slot + r], c == ncols holds the record ends.
+    uint32_t *cellmap;
+    uint32_t map_cap;            // records the map has room for
+    uint32_t *map_alloc;         // next free slot (bump allocation, one atomic per tile)
+    uint32_t *tile_hdr;          // [ntiles][2]: slot (NONE = not mapped), first record start | has_nul << 31
+    uint32_t only_unmapped;      // write kernel: leave the mapped tiles to the emit kernel
     uint32_t debug;  // diagnostic builds only: phases to skip (ablation timing)
 };
 

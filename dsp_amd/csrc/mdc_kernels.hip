@@ -150,6 +150,8 @@ enum {
     MS_STAGED = 2,
     MS_LBCNT = 3,   // events found in the look-behind region
     MS_WTOT = 4,    // 4 words: per-wave totals of the rank/event scan
+    MS_SLOT = 8,    // sizing pass: the tile's first slot in the cell map (NONE = no room)
+    MS_NOMAP = 9,   // sizing pass: a cell does not fit a map word
     MS_COUNT = 16
 };
 
@@ -571,6 +573,134 @@ __device__ __forceinline__ uint32_t desc_pack(uint32_t start, uint32_t len, uint
     return start | (len << 15) | (lvl << 30);
 }
 
+// cell map word: source start (15 bits) | source length (14) | filter level (2) | found (1)
+constexpr uint32_t MAP_MAXLEN = 1u << 14;
+__device__ __forceinline__ uint32_t map_pack(uint32_t start, uint32_t len, uint32_t lvl, bool found) {
+    return start | (len << 15) | (lvl << 29) | ((uint32_t)found << 31);
+}
+
+// what a wave needs, besides the cells' sources, to turn one column of a batch into output
+struct CellEnv {
+    const uint8_t *sdata;  // LDS image of the tile and its look-behind
+    const uint8_t *dbm;    // digit bitmap of the image from bm_lo on, addressed by byte
+    int bm_lo;
+    bool has_nul, nulcut;
+    const double *p10;
+    uint32_t W;
+    uint32_t *vmask;
+    uint8_t *wstage;  // this wave's staging area for cell bytes
+    uint32_t wstage_cap;
+};
+
+// One column of one batch, handled by one wave: lane l has records l and l + 64.  From the
+// cells' sources (start, length, filter level, found) it measures, filters and converts them
+// and, when WRITE, stores values, end offsets and the filtered bytes (staged in LDS, then
+// 16-byte stores).  gb = global byte position of the batch's first cell in the column arena,
+// rowbase = global row of the batch's first record.  Returns the column's bytes in this batch.
+template <bool WRITE>
+__device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const TileParams &P, uint32_t c, uint32_t typed,
+                                                 int lane, uint32_t RBn, uint64_t rowbase, uint64_t gb,
+                                                 const uint32_t (&cs_)[RB_PASSES], const uint32_t (&cl_)[RB_PASSES],
+                                                 const uint32_t (&cv_)[RB_PASSES], const bool (&fd_)[RB_PASSES],
+                                                 bool &deferred) {
+    const uint8_t *const sdata = E.sdata;
+    uint64_t *const valp = (WRITE && typed != T_NONE) ? P.val[c] : nullptr;
+    uint32_t cf_[RB_PASSES], cx_[RB_PASSES];
+    uint64_t clo_[RB_PASSES], chi_[RB_PASSES];  // fast cells: their bytes, ready to store
+    bool cfast_[RB_PASSES];
+    uint32_t total = 0;
+#pragma unroll
+    for (int ps = 0; ps < RB_PASSES; ++ps) {
+        const uint32_t r = ps * 64 + lane;
+        uint32_t flen = 0;
+        uint64_t elo = 0, ehi = 0;
+        bool fast = false;
+        if (r < RBn) {
+            const uint32_t s = cs_[ps], len = cl_[ps], lvl = cv_[ps];
+            const bool found = fd_[ps];
+            const bool convert = typed != T_NONE && (found || E.nulcut);
+            const uint32_t ty = (WRITE && convert) ? typed : (uint32_t)T_NONE;  // sizing needs lengths only
+            uint64_t value = 0;
+            bool valid = false;
+            if (len <= 16 && (int)s >= E.bm_lo) {
+                const uint4 w4 = lds_u128(sdata + s);
+                const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
+                const uint64_t hi = (uint64_t)w4.z | ((uint64_t)w4.w << 32);
+                const bool cutting = lvl == LVL_CHAR && E.nulcut && E.has_nul;
+                if (lvl == LVL_CHAR && ty == T_NONE && !cutting) {
+                    flen = len;
+                    elo = lo;
+                    ehi = hi;
+                    fast = true;
+                } else if (!cutting && ty != T_F32 && ty != T_BOOL) {
+                    const uint32_t boff = (uint32_t)((int)s - E.bm_lo);
+                    uint32_t dbits;
+                    __builtin_memcpy(&dbits, E.dbm + (boff >> 3), 4);
+                    fast = cell_fast(lo, hi, len, dbits >> (boff & 7), lvl, ty, E.p10, flen, value, valid, elo, ehi);
+                }
+                if (!fast) flen = cell_scan16<false>(lo, hi, len, lvl, E.nulcut, ty, E.p10, nullptr, value, valid);
+            } else if (len <= 16) {
+                const uint4 w4 = lds_u128(sdata + s);
+                flen = cell_scan16<false>((uint64_t)w4.x | ((uint64_t)w4.y << 32), (uint64_t)w4.z | ((uint64_t)w4.w << 32),
+                                          len, lvl, E.nulcut, ty, E.p10, nullptr, value, valid);
+            } else {
+                flen = cell_filter_long<false>(sdata + s, len, lvl, E.nulcut, nullptr);
+                if (ty != T_NONE) deferred = true;  // value and valid bit come from the second stage
+            }
+            if (WRITE && convert && valid) atomicOr(&E.vmask[r * E.W + (c >> 5)], 1u << (c & 31));
+            if (valp) valp[rowbase + r] = value;
+        }
+        const uint32_t incl = wave_incl_scan(flen);
+        clo_[ps] = elo;
+        chi_[ps] = ehi;
+        cfast_[ps] = fast;
+        cf_[ps] = flen;
+        cx_[ps] = total + incl - flen;
+        total += __shfl(incl, 63, 64);
+    }
+    if (WRITE) {
+        const uint32_t a = (uint32_t)(gb & 15);
+        const bool staged = a + total <= E.wstage_cap;
+        uint32_t *const offp = P.off[c];
+        uint8_t *const bytesp = P.bytes[c];
+#pragma unroll
+        for (int ps = 0; ps < RB_PASSES; ++ps) {
+            const uint32_t r = ps * 64 + lane;
+            if (r < RBn) {
+                offp[rowbase + r + 1] = (uint32_t)(gb + cx_[ps] + cf_[ps]);
+                if (cf_[ps]) {
+                    uint8_t *dst = staged ? E.wstage + a + cx_[ps] : bytesp + gb + cx_[ps];
+                    uint64_t dv;
+                    bool b1;
+                    if (cfast_[ps]) {
+                        win_store(dst, clo_[ps], chi_[ps], cf_[ps]);
+                    } else if (cl_[ps] <= 16) {
+                        const uint4 w4 = lds_u128(sdata + cs_[ps]);
+                        cell_scan16<true>((uint64_t)w4.x | ((uint64_t)w4.y << 32), (uint64_t)w4.z | ((uint64_t)w4.w << 32),
+                                          cl_[ps], cv_[ps], E.nulcut, T_NONE, nullptr, dst, dv, b1);
+                    } else {
+                        cell_filter_long<true>(sdata + cs_[ps], cl_[ps], cv_[ps], E.nulcut, dst);
+                    }
+                }
+            }
+        }
+        if (staged && total) {
+            // the wave's own LDS writes are visible to it in program order
+            uint8_t *dst = bytesp + gb;
+            const uint8_t *src = E.wstage + a;
+            uint32_t head = (16 - a) & 15;
+            if (head > total) head = total;
+            if ((uint32_t)lane < head) dst[lane] = src[lane];
+            const uint32_t body = (total - head) / 16;
+            for (uint32_t u = lane; u < body; u += 64)
+                *(uint4 *)(dst + head + u * 16) = *(const uint4 *)(src + head + u * 16);
+            const uint32_t done = head + body * 16;
+            if ((uint32_t)lane < total - done) dst[done + lane] = src[done + lane];
+        }
+    }
+    return total;
+}
+
 template <bool WRITE>
 __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -591,6 +721,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     const int lane = tid & 63, wave = tid >> 6;
     STAMP_INIT;
 
+    if (WRITE && P.only_unmapped && P.tile_hdr[2 * blockIdx.x] != NONE) return;  // the emit kernel has it
     const int64_t n = (int64_t)P.n;
     const int64_t tile_start = (int64_t)blockIdx.x * TILE;
     const int64_t tile_end = (tile_start + TILE < n) ? tile_start + TILE : n;
@@ -745,6 +876,15 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         }
     }
     const bool has_nul = ms[MS_HASNUL] != 0;
+    if (!WRITE && tid == 0) {
+        // room for this tile's records in the cell map (read after the next barrier)
+        uint32_t slot = NONE;
+        if (P.cellmap && nrec) {
+            slot = atomicAdd(P.map_alloc, nrec);
+            if (slot > P.map_cap || nrec > P.map_cap - slot) slot = NONE;
+        }
+        ms[MS_SLOT] = slot;
+    }
     const uint32_t RB = L.RB, EVCAP = L.evcap;
     const uint64_t *tb = WRITE ? P.tile_base + (uint64_t)blockIdx.x * (ncols + 1) : nullptr;
     const uint64_t row0 = WRITE ? tb[ncols] : 0;
@@ -891,25 +1031,31 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         // descriptors, lengths, typed values, offsets, staging, copy-out) stays inside the wave,
         // so no block barrier is needed until the row outputs
         bool deferred = false;
-        uint8_t *const wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
-        const uint32_t wstage_cap = L.stage_cap / (BLOCK / 64);
+        CellEnv E;
+        E.sdata = sdata;
+        E.dbm = (const uint8_t *)dbm;
+        E.bm_lo = bm_lo;
+        E.has_nul = has_nul;
+        E.nulcut = nulcut;
+        E.p10 = p10;
+        E.W = W;
+        E.vmask = vmask;
+        E.wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
+        E.wstage_cap = L.stage_cap / (BLOCK / 64);
+        const uint32_t slot = WRITE ? NONE : ms[MS_SLOT];
+        const bool mapping = !WRITE && slot != NONE;
         for (uint32_t c = wave; c < ncols && !SKIP(2); c += BLOCK / 64) {
             const uint32_t typed = cols[c].typed;
             const uint32_t clvl = cols[c].level;
-            uint64_t *const valp = (WRITE && typed != T_NONE) ? P.val[c] : nullptr;
-            uint32_t cs_[RB_PASSES], cl_[RB_PASSES], cv_[RB_PASSES], cf_[RB_PASSES], cx_[RB_PASSES];
-            uint64_t clo_[RB_PASSES], chi_[RB_PASSES];  // fast cells: their bytes, ready to store
-            bool cfast_[RB_PASSES];
-            uint32_t total = 0;
+            uint32_t cs_[RB_PASSES], cl_[RB_PASSES], cv_[RB_PASSES];
+            bool fd_[RB_PASSES];
 #pragma unroll
             for (int ps = 0; ps < RB_PASSES; ++ps) {
                 const uint32_t r = ps * 64 + lane;
-                uint32_t s = 0, len = 0, lvl = LVL_CHAR, flen = 0;
-                uint64_t elo = 0, ehi = 0;
-                bool fast = false;
+                uint32_t s = 0, len = 0, lvl = LVL_CHAR;
+                bool found = false;
                 if (r < RBn) {
                     const uint32_t idx = c * RB + r;
-                    bool found;
                     if (csv) {
                         const uint32_t d = desc[idx];
                         s = d & 0x7FFFu;
@@ -951,98 +1097,27 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                         }
                         if (found) atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
                     }
-                    const bool convert = typed != T_NONE && (found || nulcut);
-                    const uint32_t ty = (WRITE && convert) ? typed : (uint32_t)T_NONE;  // sizing needs lengths only
-                    uint64_t value = 0;
-                    bool valid = false;
-                    if (len <= 16 && (int)s >= bm_lo) {
-                        const uint4 w4 = lds_u128(sdata + s);
-                        const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
-                        const uint64_t hi = (uint64_t)w4.z | ((uint64_t)w4.w << 32);
-                        const bool cutting = lvl == LVL_CHAR && nulcut && has_nul;
-                        if (lvl == LVL_CHAR && ty == T_NONE && !cutting) {
-                            flen = len;
-                            elo = lo;
-                            ehi = hi;
-                            fast = true;
-                        } else if (!cutting && ty != T_F32 && ty != T_BOOL) {
-                            const uint32_t boff = (uint32_t)((int)s - bm_lo);
-                            uint32_t dbits;
-                            __builtin_memcpy(&dbits, (const uint8_t *)dbm + (boff >> 3), 4);
-                            fast = cell_fast(lo, hi, len, dbits >> (boff & 7), lvl, ty, p10, flen, value, valid, elo, ehi);
-                        }
-                        if (!fast)
-                            flen = cell_scan16<false>(lo, hi, len, lvl, nulcut, ty, p10, nullptr, value, valid);
-                    } else if (len <= 16) {
-                        const uint4 w4 = lds_u128(sdata + s);
-                        flen = cell_scan16<false>((uint64_t)w4.x | ((uint64_t)w4.y << 32),
-                                                  (uint64_t)w4.z | ((uint64_t)w4.w << 32), len, lvl, nulcut, ty, p10,
-                                                  nullptr, value, valid);
-                    } else {
-                        flen = cell_filter_long<false>(sdata + s, len, lvl, nulcut, nullptr);
-                        if (ty != T_NONE) deferred = true;  // value and valid bit come from the second stage
+                    if (mapping) {
+                        if (len < MAP_MAXLEN)
+                            P.cellmap[(uint64_t)c * P.map_cap + slot + rb0 + r] = map_pack(s, len, lvl, found);
+                        else
+                            ms[MS_NOMAP] = 1;
                     }
-                    if (WRITE && convert && valid) atomicOr(&vmask[r * W + (c >> 5)], 1u << (c & 31));
-                    if (valp) valp[row0 + rb0 + r] = value;
                 }
-                const uint32_t incl = wave_incl_scan(flen);
-                clo_[ps] = elo;
-                chi_[ps] = ehi;
-                cfast_[ps] = fast;
                 cs_[ps] = s;
                 cl_[ps] = len;
                 cv_[ps] = lvl;
-                cf_[ps] = flen;
-                cx_[ps] = total + incl - flen;
-                total += __shfl(incl, 63, 64);
+                fd_[ps] = found;
             }
-            if (WRITE) {
-                const uint64_t gb = tb[c] + tiletot[c];
-                const uint32_t a = (uint32_t)(gb & 15);
-                const bool staged = a + total <= wstage_cap;
-                uint32_t *const offp = P.off[c];
-                uint8_t *const bytesp = P.bytes[c];
-#pragma unroll
-                for (int ps = 0; ps < RB_PASSES; ++ps) {
-                    const uint32_t r = ps * 64 + lane;
-                    if (r < RBn) {
-                        offp[row0 + rb0 + r + 1] = (uint32_t)(gb + cx_[ps] + cf_[ps]);
-                        if (cf_[ps]) {
-                            uint8_t *dst = staged ? wstage + a + cx_[ps] : bytesp + gb + cx_[ps];
-                            uint64_t dv;
-                            bool b1;
-                            if (cfast_[ps]) {
-                                win_store(dst, clo_[ps], chi_[ps], cf_[ps]);
-                            } else if (cl_[ps] <= 16) {
-                                const uint4 w4 = lds_u128(sdata + cs_[ps]);
-                                cell_scan16<true>((uint64_t)w4.x | ((uint64_t)w4.y << 32),
-                                                  (uint64_t)w4.z | ((uint64_t)w4.w << 32), cl_[ps], cv_[ps], nulcut,
-                                                  T_NONE, nullptr, dst, dv, b1);
-                            } else {
-                                cell_filter_long<true>(sdata + cs_[ps], cl_[ps], cv_[ps], nulcut, dst);
-                            }
-                        }
-                    }
-                }
-                if (staged && total) {
-                    // the wave's own LDS writes are visible to it in program order
-                    uint8_t *dst = bytesp + gb;
-                    const uint8_t *src = wstage + a;
-                    uint32_t head = (16 - a) & 15;
-                    if (head > total) head = total;
-                    if ((uint32_t)lane < head) dst[lane] = src[lane];
-                    const uint32_t body = (total - head) / 16;
-                    for (uint32_t u = lane; u < body; u += 64)
-                        *(uint4 *)(dst + head + u * 16) = *(const uint4 *)(src + head + u * 16);
-                    const uint32_t done = head + body * 16;
-                    if ((uint32_t)lane < total - done) dst[done + lane] = src[done + lane];
-                }
-            }
+            const uint64_t gb = WRITE ? tb[c] + tiletot[c] : 0;
+            const uint32_t total = column_cells<WRITE>(E, P, c, typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
             if (lane == 0) tiletot[c] += total;  // this wave owns column c
         }
         if (WRITE && deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
         __syncthreads();
         STAMP(5);  // cells: descriptors, lengths, values, staging, copy-out
+        if (mapping && (uint32_t)tid < RBn)
+            P.cellmap[(uint64_t)ncols * P.map_cap + slot + rb0 + tid] = recend[tid + 1];
         if (WRITE && (uint32_t)tid < RBn) {
             const uint64_t row = row0 + rb0 + tid;
             if (P.rec_off) P.rec_off[row + 1] = (uint64_t)(base_pos + (int64_t)recend[tid + 1] + 1);
@@ -1060,8 +1135,150 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     if (!WRITE) {
         uint32_t *tc = P.tile_counts + (uint64_t)blockIdx.x * (ncols + 1);
         for (uint32_t c = tid; c < ncols; c += BLOCK) tc[c] = tiletot[c];
-        if (tid == 0) tc[ncols] = nrec;
+        if (tid == 0) {
+            tc[ncols] = nrec;
+            if (P.tile_hdr) {
+                // all batches are done (the loop ends with a barrier): is the tile's map complete?
+                const uint32_t slot = nrec ? ms[MS_SLOT] : 0u;
+                const bool mapped = slot != NONE && !ms[MS_NOMAP];
+                P.tile_hdr[2 * blockIdx.x] = mapped ? slot : NONE;
+                P.tile_hdr[2 * blockIdx.x + 1] = (uint32_t)s0_li | (has_nul ? 0x80000000u : 0u);
+                if (!mapped) atomicOr(P.status, ST_UNMAPPED);
+            }
+        }
     }
+}
+
+// Write pass over tiles whose cell map the sizing pass completed: no record split, no tag
+// search.  A block loads its tile (and the head of its first record from the look-behind),
+// rebuilds the digit bitmap, reads each cell's source from the map and runs the same column
+// routine as the tile kernel.  Tiles without a map are left to tile_kernel<true>.
+__global__ __launch_bounds__(BLOCK) void emit_kernel(const TileParams P) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const LdsLayout &L = P.L;
+    uint8_t *sdata = smem + L.data;
+    uint32_t *vmask = (uint32_t *)(smem + L.vmask);
+    uint32_t *fmask = (uint32_t *)(smem + L.fmask);
+    uint8_t *stage = smem + L.evlist;
+    uint64_t *dbm = (uint64_t *)(smem + L.dbm);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile = blockIdx.x;
+    const SchemaHdr *Hg = (const SchemaHdr *)P.schema;
+    const uint32_t ncols = Hg->ncols, W = Hg->words;
+    if (tile == 0) {
+        if (tid == 0 && P.rec_off) P.rec_off[0] = 0;
+        for (uint32_t c = tid; c < ncols; c += BLOCK) P.off[c][0] = 0;
+    }
+    const uint32_t slot = P.tile_hdr[2 * tile];
+    const uint32_t nrec = P.tile_counts[(uint64_t)tile * (ncols + 1) + ncols];
+    if (slot == NONE || nrec == 0) return;
+    const uint32_t hw = P.tile_hdr[2 * tile + 1];
+    const int s0_li = (int)(hw & 0x7FFFFFFFu);
+    const bool has_nul = (hw >> 31) != 0;
+
+    const int64_t n = (int64_t)P.n;
+    const int64_t tile_start = (int64_t)tile * TILE;
+    const int64_t tile_end = (tile_start + TILE < n) ? tile_start + TILE : n;
+    const int LB = (int)L.lbmax;
+    const int64_t base_pos = tile_start - LB;
+    const int ts_li = LB;
+    const int te_li = LB + (int)(tile_end - tile_start);
+    const int bm_lo = ts_li - LB_FIRST;
+
+    auto load_chunk = [&](int j) -> uint4 {
+        const int64_t pos = base_pos + (int64_t)j * CHUNK;
+        if (pos + CHUNK <= n) return *(const uint4 *)(P.data + pos);
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int k = 0; k < CHUNK; ++k)
+            if (pos + k < n) w[k >> 2] |= (uint32_t)P.data[pos + k] << (8 * (k & 3));
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = ts_li / CHUNK + k * BLOCK + tid;
+        ((uint4 *)sdata)[j] = j * CHUNK < te_li ? load_chunk(j) : make_uint4(0, 0, 0, 0);
+    }
+    for (int j = s0_li / CHUNK + tid; j < ts_li / CHUNK; j += BLOCK) ((uint4 *)sdata)[j] = load_chunk(j);
+    {
+        const uint4 *g = (const uint4 *)P.schema;
+        uint4 *s = (uint4 *)(smem + L.schema);
+        for (uint32_t i = tid; i < P.schema_bytes / 16; i += BLOCK) s[i] = g[i];
+    }
+    uint32_t *tiletot = (uint32_t *)(smem + L.coltot);
+    for (uint32_t c = tid; c < ncols; c += BLOCK) tiletot[c] = 0;
+    __syncthreads();
+    const SchemaHdr *H = (const SchemaHdr *)(smem + L.schema);
+    const DevCol *cols = (const DevCol *)(H + 1);
+    {
+        // digit bitmap of the tile and of the first look-behind window (bits of bytes in front
+        // of the first record come from stale LDS and are never looked at)
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ((const uint4 *)sdata)[(ts_li + tid * 64) / CHUNK + k];
+        dbm[LB_FIRST / 64 + tid] = digit_mask64(v);
+        if (tile_start > 0 && tid < LB_FIRST / 64) {
+            uint4 u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = ((const uint4 *)sdata)[(bm_lo + tid * 64) / CHUNK + k];
+            dbm[tid] = digit_mask64(u);
+        }
+    }
+    const uint64_t *tb = P.tile_base + (uint64_t)tile * (ncols + 1);
+    const uint64_t row0 = tb[ncols];
+    const uint32_t RB = L.RB;
+    CellEnv E;
+    E.sdata = sdata;
+    E.dbm = (const uint8_t *)dbm;
+    E.bm_lo = bm_lo;
+    E.has_nul = has_nul;
+    E.nulcut = H->carry != 0 && H->mode != MODE_CSV;
+    E.p10 = (const double *)(smem + L.schema + H->p10_off);
+    E.W = W;
+    E.vmask = vmask;
+    E.wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
+    E.wstage_cap = L.stage_cap / (BLOCK / 64);
+    bool deferred = false;
+    for (uint32_t rb0 = 0; rb0 < nrec; rb0 += RB) {
+        const uint32_t RBn = (nrec - rb0 < RB) ? nrec - rb0 : RB;
+        for (uint32_t i = tid; i < RB * W; i += BLOCK) {
+            vmask[i] = 0;
+            fmask[i] = 0;
+        }
+        __syncthreads();  // also orders the bitmap and the previous batch's row outputs
+        for (uint32_t c = wave; c < ncols; c += BLOCK / 64) {
+            const uint32_t *mp = P.cellmap + (uint64_t)c * P.map_cap + slot + rb0;
+            uint32_t cs_[RB_PASSES], cl_[RB_PASSES], cv_[RB_PASSES];
+            bool fd_[RB_PASSES];
+#pragma unroll
+            for (int ps = 0; ps < RB_PASSES; ++ps) {
+                const uint32_t r = ps * 64 + lane;
+                const uint32_t d = r < RBn ? mp[r] : 0u;
+                cs_[ps] = d & 0x7FFFu;
+                cl_[ps] = (d >> 15) & (MAP_MAXLEN - 1);
+                cv_[ps] = (d >> 29) & 3u;
+                fd_[ps] = (d >> 31) != 0;
+                if (fd_[ps]) atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
+            }
+            const uint64_t gb = tb[c] + tiletot[c];
+            const uint32_t total =
+                column_cells<true>(E, P, c, cols[c].typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
+            if (lane == 0) tiletot[c] += total;  // this wave owns column c
+        }
+        __syncthreads();
+        if ((uint32_t)tid < RBn) {
+            const uint64_t row = row0 + rb0 + tid;
+            if (P.rec_off)
+                P.rec_off[row + 1] =
+                    (uint64_t)(base_pos + (int64_t)P.cellmap[(uint64_t)ncols * P.map_cap + slot + rb0 + tid] + 1);
+            for (uint32_t w = 0; w < W; ++w) {
+                P.valid[row * W + w] = vmask[tid * W + w];
+                P.found[row * W + w] = fmask[tid * W + w];
+            }
+        }
+        __syncthreads();
+    }
+    if (deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
 }
 
 // Exclusive prefix over tiles of every counter (one block per counter).
@@ -1153,6 +1370,14 @@ hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(deferred_convert_kernel, dim3(blocks), dim3(256), 0, stream, schema, off, bytes, val, valid, found,
                        rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream) {
+    if (P.ntiles == 0) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void *)emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(emit_kernel, dim3(P.ntiles), dim3(BLOCK), P.L.total, stream, P);
     return hipGetLastError();
 }
 

@@ -94,12 +94,13 @@ typedef struct mdc_batch mdc_batch;
 typedef struct mdc_timing {
     float count_ms;  /* sizing pass (tile kernel, count mode)        */
     float scan_ms;   /* tile-offset scan                              */
-    float write_ms;  /* tile kernel, write mode: the dominant kernel  */
+    float write_ms;  /* write pass (emit kernel, plus the full write kernel if it ran) */
     float total_ms;  /* first launch to last completion               */
     uint64_t bytes_in;
     uint64_t bytes_out; /* algorithmic output bytes actually written  */
     int64_t rows;
     int tiles;
+    int full_write;  /* 1 = some tiles had no cell map and went through the full write kernel */
 } mdc_timing;
 
 /* ---- library ------------------------------------------------------------------------ */

@@ -269,3 +269,34 @@ def test_device_resident_input(port):
     assert t.rows == n and t.bytes_in == len(data) and t.write_ms > 0
     d.free()
     p.close()
+
+
+def test_tiles_without_a_cell_map_take_the_full_write_kernel(port):
+    # far more records per byte than the map is sized for: most tiles find no room in it
+    lines = b"".join(b"%d,%d\n" % (i % 7, i % 3) for i in range(150000))
+    typed = [schema.T_I64, schema.T_F64]
+    p = capi.Parser.csv(",", 2, typed=typed)
+    got = p.parse_host(lines).to_host()
+    assert p.timing().full_write == 1
+    assert_batches_equal(got, port.parse_csv(lines, ",", 2, typed=typed), "short lines")
+    # the next parse sizes the map from this one's records per byte: every tile fits
+    got = p.parse_host(lines).to_host()
+    assert p.timing().full_write == 0
+    assert_batches_equal(got, port.parse_csv(lines, ",", 2, typed=typed), "short lines, second parse")
+    p.close()
+    recs = b"<a>1</a><endl/>\n" * 60000 + b"<endl/>\n" * 50000 + b"<b>2.5</b><endl/>\n" * 1000
+    got = gpu_xml(recs, cases.SMALL)
+    assert_batches_equal(got, port.parse_xml(recs, cases.SMALL), "short records")
+
+
+def test_cell_longer_than_a_map_word_holds(port):
+    # close tag in front of the open tag: the cell is the rest of a 20,000-byte record
+    filler = b"x" * 19900
+    rec = b"</a><a>start" + filler + b"<b>7</b><endl/>\n"
+    data = b"<a>1</a><b>2</b><endl/>\n" * 300 + rec + b"<a>3</a><b>4</b><endl/>\n" * 300
+    cols = [Col("a", "char", 0), Col("b", "number", 22)]
+    p = capi.Parser.xml(cols)
+    got = p.parse_host(data).to_host()
+    assert p.timing().full_write == 1
+    assert_batches_equal(got, port.parse_xml(data, cols), "long cell")
+    p.close()
