@@ -209,7 +209,7 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         L.stage_cap = L.evcap * 3;
         o += L.evcap * 3;
         L.evt = o;
-        o += round16(RB * (npat > ncols ? npat : ncols) * 4);
+        o += round16(RB * (npat > ncols + 1 ? npat : ncols + 1) * 4);
         L.recend = o;
         o += round16((RB + 1) * 4);
         L.vmask = o;
@@ -218,6 +218,8 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         o += round16(RB * words * 4);
         L.coltot = o;
         o += round16(2 * (ncols + 1) * 4);
+        L.colout = o;
+        o += round16(ncols * 32);
         L.dbm = o;
         o += round16((LB_FIRST / 64 + BLOCK + 1) * 8);
         L.schema = o;

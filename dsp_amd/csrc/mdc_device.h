@@ -95,6 +95,7 @@ struct LdsLayout {
     uint32_t vmask;   // RB*words u32
     uint32_t fmask;   // RB*words u32
     uint32_t coltot;  // 2*(ncols+1) u32: batch totals, tile totals
+    uint32_t colout;  // ncols x 32 bytes: output pointers and tile base of every column
     uint32_t dbm;     // (LB_FIRST/64 + BLOCK + 1) u64: digit bitmap of the tile and the first look-behind window
     uint32_t schema;  // schema blob
     uint32_t misc;    // block-wide scalars

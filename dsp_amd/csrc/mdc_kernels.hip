@@ -590,6 +590,24 @@ struct CellEnv {
     uint32_t *vmask;
     uint8_t *wstage;  // this wave's staging area for cell bytes
     uint32_t wstage_cap;
+    bool nostore = false;  // diagnostic builds: measure without the column's stores
+};
+
+// pointers known to address global memory (a pointer that comes out of a table in memory is
+// generic to the compiler, which then emits the slower flat stores)
+typedef __attribute__((address_space(1))) uint8_t gmem_u8;
+typedef __attribute__((address_space(1))) uint32_t gmem_u32;
+typedef __attribute__((address_space(1))) uint64_t gmem_u64;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4 gmem_u128;
+
+// where one column's output goes (copied to LDS at kernel start: plain loads from the pointer
+// tables in global memory would queue behind the wave's outstanding stores)
+struct ColOut {
+    uint32_t *off;
+    uint8_t *bytes;
+    uint64_t *val;
+    uint64_t base;  // byte position of the tile's first cell in the column arena
 };
 
 // One column of one batch, handled by one wave: lane l has records l and l + 64.  From the
@@ -598,13 +616,13 @@ struct CellEnv {
 // 16-byte stores).  gb = global byte position of the batch's first cell in the column arena,
 // rowbase = global row of the batch's first record.  Returns the column's bytes in this batch.
 template <bool WRITE>
-__device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const TileParams &P, uint32_t c, uint32_t typed,
+__device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut &O, uint32_t c, uint32_t typed,
                                                  int lane, uint32_t RBn, uint64_t rowbase, uint64_t gb,
                                                  const uint32_t (&cs_)[RB_PASSES], const uint32_t (&cl_)[RB_PASSES],
                                                  const uint32_t (&cv_)[RB_PASSES], const bool (&fd_)[RB_PASSES],
                                                  bool &deferred) {
     const uint8_t *const sdata = E.sdata;
-    uint64_t *const valp = (WRITE && typed != T_NONE) ? P.val[c] : nullptr;
+    gmem_u64 *const valp = (WRITE && typed != T_NONE) ? (gmem_u64 *)O.val : nullptr;
     uint32_t cf_[RB_PASSES], cx_[RB_PASSES];
     uint64_t clo_[RB_PASSES], chi_[RB_PASSES];  // fast cells: their bytes, ready to store
     bool cfast_[RB_PASSES];
@@ -658,18 +676,24 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const TilePar
         cx_[ps] = total + incl - flen;
         total += __shfl(incl, 63, 64);
     }
-    if (WRITE) {
+    if (WRITE && !E.nostore) {
         const uint32_t a = (uint32_t)(gb & 15);
         const bool staged = a + total <= E.wstage_cap;
-        uint32_t *const offp = P.off[c];
-        uint8_t *const bytesp = P.bytes[c];
+        gmem_u32 *const offp = (gmem_u32 *)O.off;
+        gmem_u8 *const bytesp = (gmem_u8 *)O.bytes;
 #pragma unroll
         for (int ps = 0; ps < RB_PASSES; ++ps) {
             const uint32_t r = ps * 64 + lane;
-            if (r < RBn) {
-                offp[rowbase + r + 1] = (uint32_t)(gb + cx_[ps] + cf_[ps]);
-                if (cf_[ps]) {
-                    uint8_t *dst = staged ? E.wstage + a + cx_[ps] : bytesp + gb + cx_[ps];
+            if (r < RBn) offp[rowbase + r + 1] = (uint32_t)(gb + cx_[ps] + cf_[ps]);
+        }
+        // the cells' bytes go to `base` + their offset in the batch; called once per destination
+        // so that LDS and global stores are told apart at compile time
+        auto put_cells = [&](uint8_t *base) {
+#pragma unroll
+            for (int ps = 0; ps < RB_PASSES; ++ps) {
+                const uint32_t r = ps * 64 + lane;
+                if (r < RBn && cf_[ps]) {
+                    uint8_t *dst = base + cx_[ps];
                     uint64_t dv;
                     bool b1;
                     if (cfast_[ps]) {
@@ -683,19 +707,24 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const TilePar
                     }
                 }
             }
-        }
-        if (staged && total) {
-            // the wave's own LDS writes are visible to it in program order
-            uint8_t *dst = bytesp + gb;
-            const uint8_t *src = E.wstage + a;
-            uint32_t head = (16 - a) & 15;
-            if (head > total) head = total;
-            if ((uint32_t)lane < head) dst[lane] = src[lane];
-            const uint32_t body = (total - head) / 16;
-            for (uint32_t u = lane; u < body; u += 64)
-                *(uint4 *)(dst + head + u * 16) = *(const uint4 *)(src + head + u * 16);
-            const uint32_t done = head + body * 16;
-            if ((uint32_t)lane < total - done) dst[done + lane] = src[done + lane];
+        };
+        if (staged) {
+            put_cells(E.wstage + a);
+            if (total) {
+                // the wave's own LDS writes are visible to it in program order
+                gmem_u8 *dst = bytesp + gb;
+                const uint8_t *src = E.wstage + a;
+                uint32_t head = (16 - a) & 15;
+                if (head > total) head = total;
+                if ((uint32_t)lane < head) dst[lane] = src[lane];
+                const uint32_t body = (total - head) / 16;
+                for (uint32_t u = lane; u < body; u += 64)
+                    *(gmem_u128 *)(dst + head + u * 16) = *(const u32x4 *)(src + head + u * 16);
+                const uint32_t done = head + body * 16;
+                if ((uint32_t)lane < total - done) dst[done + lane] = src[done + lane];
+            }
+        } else {
+            put_cells((uint8_t *)(bytesp + gb));
         }
     }
     return total;
@@ -718,7 +747,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     uint64_t *dbm = (uint64_t *)(smem + L.dbm);  // digit bitmap: bit (li - bm_lo) of the LDS image
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: scalar loads for per-column data)
     STAMP_INIT;
 
     if (WRITE && P.only_unmapped && P.tile_hdr[2 * blockIdx.x] != NONE) return;  // the emit kernel has it
@@ -888,6 +917,16 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     const uint32_t RB = L.RB, EVCAP = L.evcap;
     const uint64_t *tb = WRITE ? P.tile_base + (uint64_t)blockIdx.x * (ncols + 1) : nullptr;
     const uint64_t row0 = WRITE ? tb[ncols] : 0;
+    ColOut *colout = (ColOut *)(smem + L.colout);
+    if (WRITE)
+        for (uint32_t c = tid; c < ncols; c += BLOCK) {
+            ColOut o;
+            o.off = P.off[c];
+            o.bytes = P.bytes[c];
+            o.val = P.val[c];
+            o.base = tb[c];
+            colout[c] = o;
+        }
     if (WRITE && blockIdx.x == 0) {
         if (tid == 0 && P.rec_off) P.rec_off[0] = 0;
         for (uint32_t c = tid; c < ncols; c += BLOCK) P.off[c][0] = 0;
@@ -1109,8 +1148,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 cv_[ps] = lvl;
                 fd_[ps] = found;
             }
-            const uint64_t gb = WRITE ? tb[c] + tiletot[c] : 0;
-            const uint32_t total = column_cells<WRITE>(E, P, c, typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
+            ColOut O = {};
+            if (WRITE) O = colout[c];
+            const uint64_t gb = WRITE ? O.base + tiletot[c] : 0;
+            const uint32_t total = column_cells<WRITE>(E, O, c, typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
             if (lane == 0) tiletot[c] += total;  // this wave owns column c
         }
         if (WRITE && deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
@@ -1161,8 +1202,9 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(const TileParams P) {
     uint32_t *fmask = (uint32_t *)(smem + L.fmask);
     uint8_t *stage = smem + L.evlist;
     uint64_t *dbm = (uint64_t *)(smem + L.dbm);
+    uint32_t *mapl = (uint32_t *)(smem + L.evt);  // the batch's slice of the cell map: word (c, r) at c * RB + r
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: scalar loads for per-column data)
     const uint32_t tile = blockIdx.x;
     const SchemaHdr *Hg = (const SchemaHdr *)P.schema;
     const uint32_t ncols = Hg->ncols, W = Hg->words;
@@ -1206,7 +1248,27 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(const TileParams P) {
         for (uint32_t i = tid; i < P.schema_bytes / 16; i += BLOCK) s[i] = g[i];
     }
     uint32_t *tiletot = (uint32_t *)(smem + L.coltot);
-    for (uint32_t c = tid; c < ncols; c += BLOCK) tiletot[c] = 0;
+    ColOut *colout = (ColOut *)(smem + L.colout);
+    const uint64_t *tb = P.tile_base + (uint64_t)tile * (ncols + 1);
+    for (uint32_t c = tid; c < ncols; c += BLOCK) {
+        tiletot[c] = 0;
+        ColOut o;
+        o.off = P.off[c];
+        o.bytes = P.bytes[c];
+        o.val = P.val[c];
+        o.base = tb[c];
+        colout[c] = o;
+    }
+    const uint64_t row0 = tb[ncols];
+    const uint32_t RB = L.RB;
+    // the map words of a batch, fetched together with the tile so that their latency overlaps
+    auto load_map = [&](uint32_t rb0, uint32_t RBn) {
+        for (uint32_t c = wave; c <= ncols; c += BLOCK / 64) {
+            const uint32_t *mp = P.cellmap + (uint64_t)c * P.map_cap + slot + rb0;
+            for (uint32_t r = lane; r < RBn; r += 64) mapl[c * RB + r] = mp[r];
+        }
+    };
+    load_map(0, nrec < RB ? nrec : RB);
     __syncthreads();
     const SchemaHdr *H = (const SchemaHdr *)(smem + L.schema);
     const DevCol *cols = (const DevCol *)(H + 1);
@@ -1224,9 +1286,6 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(const TileParams P) {
             dbm[tid] = digit_mask64(u);
         }
     }
-    const uint64_t *tb = P.tile_base + (uint64_t)tile * (ncols + 1);
-    const uint64_t row0 = tb[ncols];
-    const uint32_t RB = L.RB;
     CellEnv E;
     E.sdata = sdata;
     E.dbm = (const uint8_t *)dbm;
@@ -1238,16 +1297,18 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(const TileParams P) {
     E.vmask = vmask;
     E.wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
     E.wstage_cap = L.stage_cap / (BLOCK / 64);
+    E.nostore = SKIP(32);
     bool deferred = false;
     for (uint32_t rb0 = 0; rb0 < nrec; rb0 += RB) {
         const uint32_t RBn = (nrec - rb0 < RB) ? nrec - rb0 : RB;
+        if (rb0) load_map(rb0, RBn);  // (the previous batch ended with a barrier)
         for (uint32_t i = tid; i < RB * W; i += BLOCK) {
             vmask[i] = 0;
             fmask[i] = 0;
         }
         __syncthreads();  // also orders the bitmap and the previous batch's row outputs
-        for (uint32_t c = wave; c < ncols; c += BLOCK / 64) {
-            const uint32_t *mp = P.cellmap + (uint64_t)c * P.map_cap + slot + rb0;
+        for (uint32_t c = wave; c < ncols && !SKIP(16); c += BLOCK / 64) {
+            const uint32_t *mp = mapl + c * RB;
             uint32_t cs_[RB_PASSES], cl_[RB_PASSES], cv_[RB_PASSES];
             bool fd_[RB_PASSES];
 #pragma unroll
@@ -1260,9 +1321,10 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(const TileParams P) {
                 fd_[ps] = (d >> 31) != 0;
                 if (fd_[ps]) atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
             }
-            const uint64_t gb = tb[c] + tiletot[c];
+            const ColOut O = colout[c];
+            const uint64_t gb = O.base + tiletot[c];
             const uint32_t total =
-                column_cells<true>(E, P, c, cols[c].typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
+                column_cells<true>(E, O, c, cols[c].typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
             if (lane == 0) tiletot[c] += total;  // this wave owns column c
         }
         __syncthreads();
@@ -1270,7 +1332,7 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(const TileParams P) {
             const uint64_t row = row0 + rb0 + tid;
             if (P.rec_off)
                 P.rec_off[row + 1] =
-                    (uint64_t)(base_pos + (int64_t)P.cellmap[(uint64_t)ncols * P.map_cap + slot + rb0 + tid] + 1);
+                    (uint64_t)(base_pos + (int64_t)mapl[ncols * RB + tid] + 1);
             for (uint32_t w = 0; w < W; ++w) {
                 P.valid[row * W + w] = vmask[tid * W + w];
                 P.found[row * W + w] = fmask[tid * W + w];

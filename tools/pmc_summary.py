@@ -45,7 +45,7 @@ def _avg(passdir, counter, kernel_sub):
             per[row["Dispatch_Id"]] += float(row["Counter_Value"])
     return sum(per.values()) / len(per) if per else None
 
-kernel_sub = "tile_kernel<true>" if len(sys.argv) < 3 else sys.argv[2]
+kernel_sub = "emit_kernel" if len(sys.argv) < 3 else sys.argv[2]
 f, w = _avg("pmc3", "FETCH_SIZE", kernel_sub), _avg("pmc4", "WRITE_SIZE", kernel_sub)
 if f is not None and w is not None:
     t = {"kernel": kernel_sub, "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
