@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdc_parse.so")
 
 MDC_OK = 0
+MDC_STREAM_END = 1
 MDC_FILE_OPEN_FAILED = 5
 MDC_ERR_ARG = -1
 MDC_ERR_NO_DEVICE = -2
@@ -37,6 +38,7 @@ EXPORTS = [
     "mdc_parser_create_xml", "mdc_parser_create_csv", "mdc_parser_destroy",
     "mdc_parse_device", "mdc_parse_host", "mdc_parse_file", "mdc_parser_last_timing",
     "mdc_parse_xml_buffer", "mdc_parse_xml_file", "mdc_parse_csv_buffer",
+    "mdc_stream_open", "mdc_stream_next", "mdc_stream_bytes", "mdc_stream_close",
     "mdc_batch_rows", "mdc_batch_ncols", "mdc_batch_words_per_row",
     "mdc_batch_device_column", "mdc_batch_device_values", "mdc_batch_device_masks", "mdc_batch_device_recoff",
     "mdc_batch_host_column", "mdc_batch_host_values", "mdc_batch_host_masks", "mdc_batch_host_recoff",
@@ -106,6 +108,12 @@ def lib():
         L.mdc_parse_xml_file.argtypes = [ctypes.c_char_p, vp, ci, ctypes.POINTER(COpts), pp]
         L.mdc_parse_csv_buffer.argtypes = [vp, sz, ctypes.c_char_p, ci, ci, ctypes.POINTER(ci),
                                            ctypes.POINTER(COpts), pp]
+        L.mdc_stream_open.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ci, ci, pp]
+        L.mdc_stream_next.argtypes = [vp, pp, ctypes.POINTER(ci)]
+        L.mdc_stream_bytes.argtypes = [vp]
+        L.mdc_stream_bytes.restype = ctypes.c_uint64
+        L.mdc_stream_close.argtypes = [vp]
+        L.mdc_stream_close.restype = None
         L.mdc_batch_rows.restype = i64
         L.mdc_batch_rows.argtypes = [vp]
         L.mdc_batch_ncols.argtypes = [vp]
@@ -295,6 +303,26 @@ class Parser:
         t = CTiming()
         check(lib().mdc_parser_last_timing(self.h, ctypes.byref(t)))
         return t
+
+    def stream(self, paths: Sequence[str], threads: int = 4):
+        """Files (plain or gzip) in list order: yields (index, Batch) or (index, MdcError) per file;
+        reading and inflating the next files and uploading the next one overlap the parse."""
+        arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
+        st = ctypes.c_void_p()
+        check(lib().mdc_stream_open(self.h, arr, len(paths), threads, ctypes.byref(st)))
+        try:
+            while True:
+                h = ctypes.c_void_p()
+                idx = ctypes.c_int(-1)
+                rc = lib().mdc_stream_next(st, ctypes.byref(h), ctypes.byref(idx))
+                if rc == MDC_STREAM_END:
+                    return
+                if rc != MDC_OK:
+                    yield idx.value, MdcError(rc, lib().mdc_last_error().decode(errors="replace"))
+                else:
+                    yield idx.value, Batch(h.value)
+        finally:
+            lib().mdc_stream_close(st)
 
 
 class DeviceBuffer:

@@ -759,24 +759,20 @@ extern "C" int mdc_parse_host(mdc_parser *p, const void *h_data, size_t n, mdc_b
     return rc;
 }
 
+// used by mdc_stream.cpp, which is built on the public entry points
+extern "C" int mdc_internal_fail(int code, const char *msg) { return fail(code, "%s", msg); }
+extern "C" int mdc_internal_parser_device(const mdc_parser *p) { return p->dev->id; }
+
 extern "C" int mdc_parse_file(mdc_parser *p, const char *path, mdc_batch **out) {
     if (!p || !out || !path) return fail(MDC_ERR_ARG, "NULL argument");
     *out = nullptr;
-    FILE *f = fopen(path, "rb");
-    if (!f) return fail(MDC_FILE_OPEN_FAILED, "open(%s) failed", path);
-    std::vector<uint8_t> buf;
-    if (fseek(f, 0, SEEK_END) == 0) {
-        long sz = ftell(f);
-        if (sz > 0) buf.reserve((size_t)sz);
-        fseek(f, 0, SEEK_SET);
-    }
-    uint8_t tmp[1 << 16];
-    size_t got;
-    while ((got = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + got);
-    bool bad = ferror(f) != 0;
-    fclose(f);
-    if (bad) return fail(MDC_ERR_IO, "read(%s) failed", path);
-    return mdc_parse_host(p, buf.data(), buf.size(), out);
+    // a stream of one file: same reader (plain or gzip), same pinned upload
+    mdc_stream *st = nullptr;
+    int rc = mdc_stream_open(p, &path, 1, 1, &st);
+    if (rc) return rc;
+    rc = mdc_stream_next(st, out, nullptr);
+    mdc_stream_close(st);
+    return rc;
 }
 
 #ifdef MDC_PHASE_TIMING

@@ -59,6 +59,7 @@ enum {
 /* ---- status codes ------------------------------------------------------------------- */
 enum {
     MDC_OK = 0,
+    MDC_STREAM_END = 1,         /* mdc_stream_next: every file has been handed out             */
     MDC_FILE_OPEN_FAILED = 5,   /* same value as _xmltodb()'s "open failed" (xmltodb.cpp:260) */
     MDC_ERR_ARG = -1,           /* bad argument / unsupported schema (see mdc_last_error)     */
     MDC_ERR_NO_DEVICE = -2,     /* no usable HIP device: there is no CPU fallback             */
@@ -148,6 +149,24 @@ int mdc_parse_xml_file(const char *path, const mdc_col *cols, int ncols, const m
                        mdc_batch **out);
 int mdc_parse_csv_buffer(const void *h_data, size_t n, const char *sep, int bdelspace,
                          int nfields, const int *ilen, const mdc_opts *opts, mdc_batch **out);
+
+/* ---- a list of files through one parser --------------------------------------------- */
+
+/* Replaces the file loop of the reference's ingest (tools/xmltodb.cpp:147-218: for every file
+ * of the sorted list: open, read, parse) for plain files and for files compressed by
+ * tools/gzipfiles.cpp:59 (gzip, recognised by the magic bytes 1f 8b).  `threads` host threads
+ * read and inflate the files ahead into pinned buffers; the upload of file k+1 runs on a copy
+ * stream while file k is parsed.  The parser must outlive the stream and must not be used for
+ * anything else while the stream is open.  mdc_parse_file reads gzip files the same way. */
+typedef struct mdc_stream mdc_stream;
+int mdc_stream_open(mdc_parser *p, const char *const *paths, int nfiles, int threads, mdc_stream **out);
+/* The next file's batch, in list order; *index (may be NULL) receives its position in paths.
+ * MDC_OK, MDC_STREAM_END after the last file, or the file's error (MDC_FILE_OPEN_FAILED,
+ * MDC_ERR_IO, a parse error): the stream then goes on with the following file. */
+int mdc_stream_next(mdc_stream *s, mdc_batch **out, int *index);
+/* uncompressed bytes handed to the parser so far */
+uint64_t mdc_stream_bytes(const mdc_stream *s);
+void mdc_stream_close(mdc_stream *s);
 
 /* ---- batches ------------------------------------------------------------------------ */
 

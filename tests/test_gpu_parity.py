@@ -300,3 +300,65 @@ def test_cell_longer_than_a_map_word_holds(port):
     assert p.timing().full_write == 1
     assert_batches_equal(got, port.parse_xml(data, cols), "long cell")
     p.close()
+
+
+def test_file_stream_plain_gzip_and_missing(tmp_path, port):
+    import gzip
+
+    paths, expect = [], []
+    for i in range(7):
+        data, n = gen.mind_xml(rows=500 + 311 * i, first_row=10000 * i)
+        raw = data.tobytes()
+        if i == 3:
+            paths.append(str(tmp_path / "missing.xml"))
+            expect.append(None)
+            continue
+        if i % 2 == 0:
+            f = tmp_path / f"obs_{i}.xml.gz"
+            if i == 4:  # two gzip members in one file
+                half = raw.rfind(b"\n", 0, len(raw) // 2) + 1
+                f.write_bytes(gzip.compress(raw[:half], 6) + gzip.compress(raw[half:], 1))
+            else:
+                f.write_bytes(gzip.compress(raw, 6))
+        else:
+            f = tmp_path / f"obs_{i}.xml"
+            f.write_bytes(raw)
+        paths.append(str(f))
+        expect.append(port.parse_xml(data, schema.ZHOBTMIND))
+    empty = tmp_path / "empty.xml"
+    empty.write_bytes(b"")
+    paths.append(str(empty))
+    expect.append(port.parse_xml(b"", schema.ZHOBTMIND))
+    bad = tmp_path / "broken.xml.gz"
+    bad.write_bytes(gzip.compress(b"<obtid>1</obtid><endl/>\n" * 1000)[:-20])
+    paths.append(str(bad))
+    expect.append("io")
+    for threads in (1, 3):
+        p = capi.Parser.xml(schema.ZHOBTMIND)
+        seen = []
+        for idx, b in p.stream(paths, threads=threads):
+            seen.append(idx)
+            if expect[idx] is None:
+                assert isinstance(b, capi.MdcError) and b.code == capi.MDC_FILE_OPEN_FAILED
+            elif isinstance(expect[idx], str):
+                assert isinstance(b, capi.MdcError) and b.code == capi.MDC_ERR_IO
+            else:
+                assert_batches_equal(b.to_host(), expect[idx], f"file {idx}, {threads} threads")
+                b.free()
+        assert seen == list(range(len(paths)))
+        p.close()
+
+
+def test_parse_file_reads_gzip(tmp_path, port):
+    import gzip
+
+    data, n = gen.mind_xml(rows=3000)
+    f = tmp_path / "obs.xml.gz"
+    f.write_bytes(gzip.compress(data.tobytes(), 6))
+    p = capi.Parser.xml(schema.ZHOBTMIND)
+    got = p.parse_file(str(f)).to_host()
+    assert_batches_equal(got, port.parse_xml(data, schema.ZHOBTMIND), "gzip file")
+    with pytest.raises(capi.MdcError) as e:
+        p.parse_file(str(tmp_path / "nope.xml"))
+    assert e.value.code == capi.MDC_FILE_OPEN_FAILED
+    p.close()
