@@ -41,8 +41,27 @@ __device__ __forceinline__ uint32_t bytes_eq(uint32_t w, uint32_t pat4) {
     uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
     return ~(t | 0x7F7F7F7Fu);
 }
+// the same for a pattern byte below 0x80: with the high bits set aside, 0x80 - (byte ^ pat) keeps
+// bit 7 only for a zero difference and never borrows from the next byte.  The two terms that do
+// not depend on the pattern are shared by all masks made from one word.
+__device__ __forceinline__ uint32_t bytes_eq7(uint32_t w, uint32_t pat4) {
+    return (0x80808080u - ((w & 0x7F7F7F7Fu) ^ pat4)) & ~w & 0x80808080u;
+}
 // gathers the four 0x80 flags of m into bits 0..3
 __device__ __forceinline__ uint32_t pack4(uint32_t m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xFu; }
+
+// Packs the 0x80 flags of eight words into one 32-bit mask, bit 4k+b = byte b of word k: a
+// byte-wise dot product with the weights 1,2,4,8 (16..128 for the odd word of a pair) turns two
+// words into 128 * (their eight bits); the four pairs are then shifted into place.
+__device__ __forceinline__ uint32_t pack32(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3, uint32_t f4, uint32_t f5,
+                                           uint32_t f6, uint32_t f7) {
+    // a flag is 0x80 = 128, so every pair's sum is 128 * (its eight bits): bits 7..14
+    const uint32_t a0 = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false);
+    const uint32_t a1 = __builtin_amdgcn_udot4(f3, 0x80402010u, __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false), false);
+    const uint32_t a2 = __builtin_amdgcn_udot4(f5, 0x80402010u, __builtin_amdgcn_udot4(f4, 0x08040201u, 0u, false), false);
+    const uint32_t a3 = __builtin_amdgcn_udot4(f7, 0x80402010u, __builtin_amdgcn_udot4(f6, 0x08040201u, 0u, false), false);
+    return (a0 >> 7) | (a1 << 1) | (a2 << 9) | (a3 << 17);
+}
 
 __device__ __forceinline__ uint32_t mask16_eq(const uint4 &v, uint32_t pat4) {
     return pack4(bytes_eq(v.x, pat4)) | (pack4(bytes_eq(v.y, pat4)) << 4) | (pack4(bytes_eq(v.z, pat4)) << 8) |
@@ -169,9 +188,25 @@ __device__ __forceinline__ uint4 lds_u128(const uint8_t *p) {
 
 // 64-bit byte-equality mask of the 64 bytes held in four dwordx4 registers
 __device__ __forceinline__ uint64_t mask64_eq(const uint4 (&v)[4], uint32_t pat4) {
-    const uint64_t lo = (uint64_t)mask16_eq(v[0], pat4) | ((uint64_t)mask16_eq(v[1], pat4) << 16);
-    const uint64_t hi = (uint64_t)mask16_eq(v[2], pat4) | ((uint64_t)mask16_eq(v[3], pat4) << 16);
-    return lo | (hi << 32);
+    const uint32_t lo = pack32(bytes_eq7(v[0].x, pat4), bytes_eq7(v[0].y, pat4), bytes_eq7(v[0].z, pat4),
+                               bytes_eq7(v[0].w, pat4), bytes_eq7(v[1].x, pat4), bytes_eq7(v[1].y, pat4),
+                               bytes_eq7(v[1].z, pat4), bytes_eq7(v[1].w, pat4));
+    const uint32_t hi = pack32(bytes_eq7(v[2].x, pat4), bytes_eq7(v[2].y, pat4), bytes_eq7(v[2].z, pat4),
+                               bytes_eq7(v[2].w, pat4), bytes_eq7(v[3].x, pat4), bytes_eq7(v[3].y, pat4),
+                               bytes_eq7(v[3].z, pat4), bytes_eq7(v[3].w, pat4));
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+// does any of the 64 bytes equal zero?
+__device__ __forceinline__ bool any_zero64(const uint4 (&v)[4]) {
+    uint32_t z = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        z |= (v[k].x - 0x01010101u) & ~v[k].x;
+        z |= (v[k].y - 0x01010101u) & ~v[k].y;
+        z |= (v[k].z - 0x01010101u) & ~v[k].z;
+        z |= (v[k].w - 0x01010101u) & ~v[k].w;
+    }
+    return (z & 0x80808080u) != 0;
 }
 
 // is the '\n' at LDS index p a record terminator (preceded by endbz)?  All bytes involved are
@@ -384,18 +419,20 @@ __device__ __forceinline__ uint32_t cell_scan16(uint64_t lo, uint64_t hi, uint32
 
 // exact per-byte digit flags (0x80 where the byte is '0'..'9')
 __device__ __forceinline__ uint32_t digit_flags(uint32_t w) {
-    const uint32_t y = w ^ 0x30303030u;
-    const uint32_t f = ((y & 0x7F7F7F7Fu) + 0x76767676u) | y;
-    return ~f & 0x80808080u;
+    // (byte & 0x7F) ^ 0x30 is 0..9 for a digit; adding 0x76 sets bit 7 for everything above
+    const uint32_t s = ((w & 0x7F7F7F7Fu) ^ 0x30303030u) + 0x76767676u;
+    return ~s & ~w & 0x80808080u;
 }
 __device__ __forceinline__ uint32_t digit_mask16(const uint4 &v) {
     return pack4(digit_flags(v.x)) | (pack4(digit_flags(v.y)) << 4) | (pack4(digit_flags(v.z)) << 8) |
            (pack4(digit_flags(v.w)) << 12);
 }
 __device__ __forceinline__ uint64_t digit_mask64(const uint4 (&v)[4]) {
-    const uint64_t lo = (uint64_t)digit_mask16(v[0]) | ((uint64_t)digit_mask16(v[1]) << 16);
-    const uint64_t hi = (uint64_t)digit_mask16(v[2]) | ((uint64_t)digit_mask16(v[3]) << 16);
-    return lo | (hi << 32);
+    const uint32_t lo = pack32(digit_flags(v[0].x), digit_flags(v[0].y), digit_flags(v[0].z), digit_flags(v[0].w),
+                               digit_flags(v[1].x), digit_flags(v[1].y), digit_flags(v[1].z), digit_flags(v[1].w));
+    const uint32_t hi = pack32(digit_flags(v[2].x), digit_flags(v[2].y), digit_flags(v[2].z), digit_flags(v[2].w),
+                               digit_flags(v[3].x), digit_flags(v[3].y), digit_flags(v[3].z), digit_flags(v[3].w));
+    return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
 // byte p (0..15) of the 16-byte window (lo, hi)
@@ -838,7 +875,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         for (int k = 0; k < 4; ++k) v[k] = ((const uint4 *)sdata)[my_li / CHUNK + k];
         uint64_t nlm = mask64_eq(v, 0x0A0A0A0Au);
         em = csv ? 0 : mask64_eq(v, 0x3C3C3C3Cu);
-        if (mask64_eq(v, 0)) ms[MS_HASNUL] = 1;
+        if (any_zero64(v)) ms[MS_HASNUL] = 1;
         dbm[LB_FIRST / 64 + tid] = digit_mask64(v);
         if (tile_start > 0 && tid < LB_FIRST / 64) {  // and for the first look-behind window
             uint4 u[4];
