@@ -22,6 +22,7 @@
 namespace mdc {
 hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t stream);
 hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream);
+uint32_t scan_segments(uint32_t ntiles);
 hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt,
                              hipStream_t stream);
 hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_t *const *bytes,
@@ -516,7 +517,7 @@ static int ensure_workspace(mdc_parser *p, size_t ntiles) {
     p->d_hdr = (uint32_t *)h;
     rc = dev_alloc(p->dev, ntiles * ncnt * 4, &a);
     if (rc) return rc;
-    rc = dev_alloc(p->dev, (ntiles + 1) * ncnt * 8, &b);
+    rc = dev_alloc(p->dev, (ntiles + 1 + scan_segments((uint32_t)ntiles)) * ncnt * 8, &b);
     if (rc) {
         dev_free(p->dev, a);
         return rc;

@@ -1380,34 +1380,68 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(const TileParams P) {
     if (deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
 }
 
-// Exclusive prefix over tiles of every counter (one block per counter).
-__global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t *counts, uint64_t *base, uint32_t ntiles,
-                                                          uint32_t ncnt) {
-    __shared__ uint64_t wtot[16];
-    __shared__ uint64_t carry_s;
-    const uint32_t j = blockIdx.x;
+// Exclusive prefix over tiles of every counter, in two small kernels.  (1) One block per
+// (segment of SCAN_SEG tiles, counter): prefix inside the segment, segment total.  (2) The same
+// grid: every block sums the totals of the segments in front of its own and adds that to its
+// prefixes; the last segment's blocks also write the grand totals (row ntiles of `base`).
+constexpr uint32_t SCAN_SEG = 4096;
+__device__ __forceinline__ uint64_t block_incl_scan1024(uint64_t v, uint64_t *wtot, uint64_t &total) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t t0 = 0; t0 < ntiles; t0 += 1024) {
-        const uint32_t t = t0 + tid;
-        uint64_t v = t < ntiles ? counts[(uint64_t)t * ncnt + j] : 0;
-        uint64_t incl = v;
+    uint64_t incl = v;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint64_t u = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += u;
-        }
-        if (lane == 63) wtot[wave] = incl;
-        __syncthreads();
-        uint64_t b = carry_s;
-        for (int w = 0; w < wave; ++w) b += wtot[w];
-        if (t < ntiles) base[(uint64_t)t * ncnt + j] = b + incl - v;
-        __syncthreads();
-        if (tid == 1023) carry_s = b + incl;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t u = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += u;
     }
-    if (tid == 0) base[(uint64_t)ntiles * ncnt + j] = carry_s;
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint64_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint64_t t = wtot[w];
+        if (w < wave) before += t;
+        all += t;
+    }
+    total = all;
+    return before + incl;
+}
+
+__global__ __launch_bounds__(1024) void scan_local_kernel(const uint32_t *counts, uint64_t *base, uint64_t *segtot,
+                                                          uint32_t ntiles, uint32_t ncnt) {
+    __shared__ uint64_t wtot[16];
+    const uint32_t seg = blockIdx.x, j = blockIdx.y;
+    const uint32_t t0 = seg * SCAN_SEG + threadIdx.x * 4;
+    uint32_t v[4];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = t0 + i < ntiles ? counts[(uint64_t)(t0 + i) * ncnt + j] : 0u;
+        sum += v[i];
+    }
+    uint64_t total;
+    uint64_t run = block_incl_scan1024(sum, wtot, total) - sum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (t0 + i < ntiles) base[(uint64_t)(t0 + i) * ncnt + j] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == 0) segtot[(uint64_t)seg * ncnt + j] = total;
+}
+
+__global__ __launch_bounds__(1024) void scan_add_kernel(uint64_t *base, const uint64_t *segtot, uint32_t ntiles,
+                                                        uint32_t ncnt) {
+    __shared__ uint64_t wtot[16];
+    const uint32_t seg = blockIdx.x, j = blockIdx.y;
+    uint64_t part = 0;
+    for (uint32_t s = threadIdx.x; s < seg; s += 1024) part += segtot[(uint64_t)s * ncnt + j];
+    uint64_t pre;
+    (void)block_incl_scan1024(part, wtot, pre);
+    const uint32_t t0 = seg * SCAN_SEG + threadIdx.x * 4;
+    if (seg)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (t0 + i < ntiles) base[(uint64_t)(t0 + i) * ncnt + j] += pre;
+    if (seg == gridDim.x - 1 && threadIdx.x == 0) base[(uint64_t)ntiles * ncnt + j] = pre + segtot[(uint64_t)seg * ncnt + j];
 }
 
 // Expands a compact column into fixed-stride NUL-terminated slots (the array-bind layout).
@@ -1493,9 +1527,15 @@ hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t strea
     return hipGetLastError();
 }
 
+// base holds (ntiles + 1 + segments) rows of ncnt counters: prefixes, totals, segment totals
+uint32_t scan_segments(uint32_t ntiles) { return ntiles ? (ntiles + SCAN_SEG - 1) / SCAN_SEG : 1; }
+
 hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt,
                              hipStream_t stream) {
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(ncnt), dim3(1024), 0, stream, counts, base, ntiles, ncnt);
+    const uint32_t nseg = scan_segments(ntiles);
+    uint64_t *segtot = base + (uint64_t)(ntiles + 1) * ncnt;
+    hipLaunchKernelGGL(scan_local_kernel, dim3(nseg, ncnt), dim3(1024), 0, stream, counts, base, segtot, ntiles, ncnt);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(nseg, ncnt), dim3(1024), 0, stream, base, segtot, ntiles, ncnt);
     return hipGetLastError();
 }
 
