@@ -210,7 +210,7 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         L.stage_cap = L.evcap * 3;
         o += L.evcap * 3;
         L.evt = o;
-        o += round16(RB * (npat > ncols + 1 ? npat : ncols + 1) * 4);
+        o += round16(RB * (npat > ncols + 2 ? npat : ncols + 2) * 4);
         L.recend = o;
         o += round16((RB + 1) * 4);
         L.vmask = o;

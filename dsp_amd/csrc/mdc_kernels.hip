@@ -834,6 +834,9 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     const HtEntry *ht = (const HtEntry *)((const uint8_t *)cols + ((ncols * sizeof(DevCol) + 15) & ~15u));
     const bool csv = H->mode == MODE_CSV;
     const bool carry = H->carry != 0;
+    // delimited mode, sizing pass, one-byte separator: separators are collected like tag events
+    // and the field descriptors are made in parallel (otherwise: one lane walks each record)
+    const bool sepfast = csv && !WRITE && H->sep_len == 1 && H->sep[0] < 0x80;
     uint32_t *coltot = (uint32_t *)(smem + L.coltot);  // totals of the current batch
     uint32_t *tiletot = coltot + (ncols + 1);          // totals of the batches done so far
     for (uint32_t c = tid; c < ncols + 1; c += BLOCK) tiletot[c] = 0;
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = ((const uint4 *)sdata)[my_li / CHUNK + k];
         uint64_t nlm = mask64_eq(v, 0x0A0A0A0Au);
-        em = csv ? 0 : mask64_eq(v, 0x3C3C3C3Cu);
+        em = !csv ? mask64_eq(v, 0x3C3C3C3Cu) : sepfast ? mask64_eq(v, rep4(H->sep[0])) : 0;
         if (any_zero64(v)) ms[MS_HASNUL] = 1;
         dbm[LB_FIRST / 64 + tid] = digit_mask64(v);
         if (tile_start > 0 && tid < LB_FIRST / 64) {  // and for the first look-behind window
@@ -970,6 +973,19 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     }
     if (tid == 0) recend[0] = (uint32_t)(s0_li - 1);
     const uint32_t seplen = H->sep_len;
+    // all separators of the tile, in input order (the staging area is not used by the sizing pass)
+    const bool fastcsv = sepfast && nev_tile <= EVCAP + EVCAP / 2;
+    const bool slow0 = fastcsv && s0_li < ts_li;  // the first record starts in the look-behind: walked by one lane
+    uint32_t *e0 = desc + ncols * RB;             // first separator of every record of the batch (RB + 1 entries)
+    if (fastcsv) {
+        uint64_t m = em;
+        uint32_t idx = ev_base;
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            evpos[idx++] = (uint16_t)(my_li + b);
+        }
+    }
     const int jlb0 = s0_li / CHUNK, jlb1 = ts_li / CHUNK;  // look-behind chunks of the first record
     STAMP(1);  // classify + rank scan
 
@@ -989,8 +1005,12 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 const int b = __builtin_ctzll(t);
                 t &= t - 1;
                 if (r >= rb0 && r < rb0 + RBn) recend[r - rb0 + 1] = (uint32_t)(my_li + b);
+                // the record behind this terminator starts with the separators that follow it
+                if (fastcsv && r + 1 >= rb0 && r + 1 <= rb0 + RBn)
+                    e0[r + 1 - rb0] = ev_base + (uint32_t)__builtin_popcountll(em & ((1ull << b) - 1));
                 ++r;
             }
+            if (fastcsv && rb0 == 0 && tid == 0) e0[0] = 0;
         }
         __syncthreads();
         STAMP(2);  // clears
@@ -1037,9 +1057,43 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         STAMP(3);  // events
 
         // ---- E. cells: descriptor, length, typed value
-        if (csv) {
+        if (fastcsv) {
+            // one lane per (field, record): field c lies between the record's separators c-1 and c
+            const uint32_t nitems = ncols * RBn;
+            const uint32_t magic = 0xFFFFFFFFu / RBn + 1;  // i / RBn == umulhi(i, magic) for i < 2^15, RBn <= 256
+            for (uint32_t i = tid; i < nitems; i += BLOCK) {
+                const uint32_t c = RBn == 1 ? i : __umulhi(i, magic);
+                const uint32_t r = i - c * RBn;
+                if (r == 0 && rb0 == 0 && slow0) continue;
+                const uint32_t rs = recend[r] + 1, re = recend[r + 1];
+                const uint32_t first = e0[r], nsep = e0[r + 1] - first;
+                uint32_t fs = re, fl = 0;
+                if (c <= nsep) {
+                    fs = c ? (uint32_t)evpos[first + c - 1] + 1 : rs;
+                    fl = (c < nsep ? (uint32_t)evpos[first + c] : re) - fs;
+                    if (H->bdelspace) {
+                        // deletelchr then deleterchr with its "pos != 0" test
+                        // (public/_public.cpp:24-31, :52-59)
+                        while (fl && sdata[fs] == ' ') {
+                            ++fs;
+                            --fl;
+                        }
+                        if (fl) {
+                            uint32_t lastp = fl - 1;
+                            while (sdata[fs + lastp] == ' ') --lastp;  // fs itself is not a blank
+                            if (lastp != 0) fl = lastp + 1;
+                        }
+                    }
+                    const int cl = cols[c].collen;
+                    if (cl > 0 && (uint32_t)cl < fl) fl = (uint32_t)cl;
+                    atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
+                }
+                desc[c * RB + r] = desc_pack(fs, fl, LVL_CHAR);
+            }
+        }
+        if (csv && (!fastcsv || (slow0 && rb0 == 0))) {
             // greedy left-to-right separator search, one lane per record (ccmdstr::splittocmd)
-            if ((uint32_t)tid < RBn) {
+            if ((uint32_t)tid < (fastcsv ? 1u : RBn)) {
                 const uint32_t r = tid;
                 const uint32_t rs = recend[r] + 1, re = recend[r + 1];
                 uint32_t fmw = 0;
@@ -1097,8 +1151,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                     }
                 }
             }
-            __syncthreads();
         }
+        if (csv) __syncthreads();
         STAMP(4);  // delimited descriptors
 
         const bool nulcut = carry && !csv;

@@ -362,3 +362,29 @@ def test_parse_file_reads_gzip(tmp_path, port):
         p.parse_file(str(tmp_path / "nope.xml"))
     assert e.value.code == capi.MDC_FILE_OPEN_FAILED
     p.close()
+
+
+def test_delimited_tiles_dense_with_separators(port):
+    # more separators per tile than the parallel field builder keeps: those tiles use the walker
+    dense = b",,,,,,,,,,,,,,,\n" * 6000
+    mixed = dense + b"".join(b"%d,%d.5,x\n" % (i, i) for i in range(5000)) + dense[:4000]
+    for data in (dense, mixed):
+        got = gpu_csv(data, ",", 4, typed=[schema.T_I64, schema.T_F64, schema.T_NONE, schema.T_NONE])
+        exp = port.parse_csv(data, ",", 4, typed=[schema.T_I64, schema.T_F64, schema.T_NONE, schema.T_NONE])
+        assert_batches_equal(got, exp, "dense separators")
+
+
+@pytest.mark.parametrize("bdel", [False, True])
+def test_delimited_long_batch_with_trim(port, bdel):
+    rng = np.random.default_rng(5)
+    lines = []
+    for i in range(40000):
+        f = [str(int(rng.integers(0, 10 ** int(rng.integers(1, 9))))) for _ in range(int(rng.integers(1, 9)))]
+        if i % 7 == 0:
+            f = [" " * int(rng.integers(0, 3)) + x + " " * int(rng.integers(0, 3)) for x in f]
+        lines.append(",".join(f))
+    data = ("\n".join(lines) + "\n").encode()
+    typed = [schema.T_I64, schema.T_F64, schema.T_U32, schema.T_NONE, schema.T_I32, schema.T_NONE]
+    got = gpu_csv(data, ",", 6, typed=typed, bdelspace=bdel, ilen=[0, 5, 0, 3, 0, 0])
+    exp = port.parse_csv(data, ",", 6, ilen=[0, 5, 0, 3, 0, 0], typed=typed, bdelspace=bdel)
+    assert_batches_equal(got, exp, "delimited, many tiles")
