@@ -170,8 +170,9 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": ("1 GiB synthetic ZHOBTMIND surface-observation XML batch -> 11 columns"
-                             if a.workload == "xml" else "synthetic ZHOBTMIND delimited batch, ccmdstr split -> 10 fields"),
+                "workload": ("%.3g GiB synthetic ZHOBTMIND surface-observation XML batch -> 11 columns" % (dbuf.n / 2**30)
+                             if a.workload == "xml" else
+                             "%.3g GiB synthetic ZHOBTMIND delimited batch, ccmdstr split -> 10 fields" % (dbuf.n / 2**30)),
                 "bytes_per_gpu": dbuf.n, "records_per_gpu": rows, "sharding": "one batch per GPU, no collective",
             },
             "records_per_s": round(total_rows * k / elapsed, 1),
