@@ -154,6 +154,7 @@ struct mdc_parser {
     std::vector<uint8_t> blob;
     void *d_blob = nullptr;
     LdsLayout Ls[3]{};  // one layout per look-behind level
+    LdsLayout LEs[3]{}; // ... and the emit kernel's
     int lb_level = 0;   // level that fitted the previous parse
     // workspace
     uint32_t *d_counts = nullptr;
@@ -231,6 +232,40 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         L.RB = RB;
         if (o <= 40 * 1024 || RB <= 8) break;
         if (RB > 64 && lbmax > 1536) break;  // the larger look-behind configurations trade occupancy
+        RB = RB > 16 ? RB - 8 : RB / 2;
+    }
+}
+
+// The emit kernel's LDS: tile image, map slice (in `evt`), staging (in `evlist`), masks,
+// schema; small enough for five blocks per CU at the first look-behind level.
+static void compute_emit_layout(uint32_t ncols, uint32_t words, uint32_t lbmax, LdsLayout &L) {
+    uint32_t RB = 112;
+    for (;;) {
+        uint32_t o = 0;
+        L = LdsLayout{};
+        L.lbmax = lbmax;
+        L.data = o;
+        o += round16(TILE + lbmax + DATA_SLACK);
+        L.evlist = o;
+        L.evcap = 0;
+        L.stage_cap = 6144;
+        o += L.stage_cap;
+        L.evt = o;
+        o += round16(RB * (ncols + 1) * 4);
+        L.vmask = o;
+        o += round16(RB * words * 4);
+        L.fmask = o;
+        o += round16(RB * words * 4);
+        L.coltot = o;
+        o += round16(2 * (ncols + 1) * 4);
+        L.colout = o;
+        o += round16(ncols * 32);
+        L.schema = o;
+        o += (uint32_t)sizeof(SchemaHdr) + round16(ncols * (uint32_t)sizeof(DevCol)) + 192;  // header, columns, 10^k
+        L.total = o;
+        L.RB = RB;
+        if (o <= 32 * 1024 || RB <= 8) break;
+        if (RB > 64 && lbmax > 1536) break;
         RB = RB > 16 ? RB - 8 : RB / 2;
     }
 }
@@ -386,6 +421,7 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
     }
     for (int lv = 0; lv < 3; ++lv) {
         compute_layout(ncols, npat, p->words, (uint32_t)p->blob.size(), LB_LEVELS[lv], p->Ls[lv]);
+        compute_emit_layout(ncols, p->words, LB_LEVELS[lv], p->LEs[lv]);
         if (p->Ls[lv].total > 160 * 1024)
             return fail(MDC_ERR_ARG, "schema too large for LDS (%u bytes)", p->Ls[lv].total);
     }
@@ -694,7 +730,9 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     P.found = b->d_found;
     HIP_TRY(hipEventRecord(p->ev[2], s));
     // tiles with a complete cell map take the short write kernel, the others the full one
+    P.L = p->LEs[p->lb_level];
     hipError_t le = launch_emit_kernel(P, s);
+    P.L = p->Ls[p->lb_level];
     if (le == hipSuccess && unmapped) {
         P.only_unmapped = 1;
         le = launch_tile_kernel(true, P, s);

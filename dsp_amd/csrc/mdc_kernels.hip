@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 
 #include "mdc_device.h"
+#include <cstdlib>
+
 #include "mdc_numparse.h"
 #include "mdc_bignum.h"
 
@@ -225,15 +227,19 @@ __device__ __forceinline__ bool is_term(const uint8_t *sdata, const SchemaHdr *H
     return true;
 }
 
-// Tag lookup for the '<' at LDS index q: one unaligned 8-byte read gives the key, ONE probe of
-// the perfect-hash table finds the entry (or none); a hit lowers first_pos[pattern][record].
-// Entries that share a key are chained and told apart by the rest of their text.
-__device__ __forceinline__ void match_tag(const uint8_t *sdata, const SchemaHdr *H, const DevCol *cols,
-                                          const HtEntry *ht, uint32_t q, uint32_t *evt, uint32_t rl, uint32_t RB) {
-    const uint32_t a = q + 1;
-    const uint64_t w = lds_u64(sdata + a);
+// Tag lookup for the '<' at LDS index q, in three steps so that a lane can keep several events
+// in flight (every step starts with an LDS access whose latency the others hide):
+//   tag_key    one unaligned 8-byte read: the key = text up to and including '>' (at most 8 bytes)
+//   tag_probe  ONE probe of the perfect-hash table (32-byte entry)
+//   tag_apply  a hit lowers first_pos[pattern][record]; entries that share a key are chained
+//              and told apart by the rest of their text
+struct TagKey {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ TagKey tag_key(const uint8_t *sdata, uint32_t q) {
+    const uint64_t w = lds_u64(sdata + q + 1);
     uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-    const uint32_t glo = bytes_eq(lo, 0x3E3E3E3Eu), ghi = bytes_eq(hi, 0x3E3E3E3Eu);
+    const uint32_t glo = bytes_eq7(lo, 0x3E3E3E3Eu), ghi = bytes_eq7(hi, 0x3E3E3E3Eu);
     if (glo) {
         const uint32_t g = (uint32_t)__builtin_ctz(glo) >> 3;
         lo &= 0xFFFFFFFFu >> (8 * (3 - g));
@@ -242,9 +248,19 @@ __device__ __forceinline__ void match_tag(const uint8_t *sdata, const SchemaHdr 
         const uint32_t g = (uint32_t)__builtin_ctz(ghi) >> 3;
         hi &= 0xFFFFFFFFu >> (8 * (3 - g));
     }
-    uint32_t slot = ht_hash(lo, hi, H->ht_seed) & H->ht_mask;
-    const uint4 e0 = *(const uint4 *)&ht[slot];
-    if (!(e0.z >> 31) || e0.x != lo || e0.y != hi) return;
+    TagKey k;
+    k.lo = lo;
+    k.hi = hi;
+    return k;
+}
+__device__ __forceinline__ uint32_t tag_slot(const SchemaHdr *H, const TagKey &k) {
+    return ht_hash(k.lo, k.hi, H->ht_seed) & H->ht_mask;
+}
+__device__ __forceinline__ void tag_apply(const uint8_t *sdata, const DevCol *cols, const HtEntry *ht, uint32_t q,
+                                          const TagKey &k, uint32_t slot, const uint4 &e0, uint32_t *evt, uint32_t rl,
+                                          uint32_t RB) {
+    if (!(e0.z >> 31) || e0.x != k.lo || e0.y != k.hi) return;
+    const uint32_t a = q + 1;
     for (;;) {
         const HtEntry &e = ht[slot];
         const uint32_t meta = e.meta;
@@ -255,8 +271,8 @@ __device__ __forceinline__ void match_tag(const uint8_t *sdata, const SchemaHdr 
             ok = (((uint32_t)w2 ^ e.k2lo) & e.m2lo) == 0 && (((uint32_t)(w2 >> 32) ^ e.k2hi) & e.m2hi) == 0;
             if (ok && (meta & 0x40000000u)) {
                 const uint8_t *nm = cols[col].name;
-                for (uint32_t k = 16; k < tlen; ++k)
-                    if (sdata[a + k] != nm[k - kind]) {
+                for (uint32_t k2 = 16; k2 < tlen; ++k2)
+                    if (sdata[a + k2] != nm[k2 - kind]) {
                         ok = false;
                         break;
                     }
@@ -267,6 +283,13 @@ __device__ __forceinline__ void match_tag(const uint8_t *sdata, const SchemaHdr 
         slot = e.next;
         if (!slot) break;
     }
+}
+__device__ __forceinline__ void match_tag(const uint8_t *sdata, const SchemaHdr *H, const DevCol *cols,
+                                          const HtEntry *ht, uint32_t q, uint32_t *evt, uint32_t rl, uint32_t RB) {
+    const TagKey k = tag_key(sdata, q);
+    const uint32_t slot = tag_slot(H, k);
+    const uint4 e0 = *(const uint4 *)&ht[slot];
+    tag_apply(sdata, cols, ht, q, k, slot, e0, evt, rl, RB);
 }
 
 // Cells longer than 16 source bytes: filter only (length, or the surviving bytes).  Their
@@ -424,8 +447,11 @@ __device__ __forceinline__ uint32_t digit_flags(uint32_t w) {
     return ~s & ~w & 0x80808080u;
 }
 __device__ __forceinline__ uint32_t digit_mask16(const uint4 &v) {
-    return pack4(digit_flags(v.x)) | (pack4(digit_flags(v.y)) << 4) | (pack4(digit_flags(v.z)) << 8) |
-           (pack4(digit_flags(v.w)) << 12);
+    const uint32_t a0 = __builtin_amdgcn_udot4(digit_flags(v.y), 0x80402010u,
+                                               __builtin_amdgcn_udot4(digit_flags(v.x), 0x08040201u, 0u, false), false);
+    const uint32_t a1 = __builtin_amdgcn_udot4(digit_flags(v.w), 0x80402010u,
+                                               __builtin_amdgcn_udot4(digit_flags(v.z), 0x08040201u, 0u, false), false);
+    return (a0 >> 7) | (a1 << 1);
 }
 __device__ __forceinline__ uint64_t digit_mask64(const uint4 (&v)[4]) {
     const uint32_t lo = pack32(digit_flags(v[0].x), digit_flags(v[0].y), digit_flags(v[0].z), digit_flags(v[0].w),
@@ -619,7 +645,7 @@ __device__ __forceinline__ uint32_t map_pack(uint32_t start, uint32_t len, uint3
 // what a wave needs, besides the cells' sources, to turn one column of a batch into output
 struct CellEnv {
     const uint8_t *sdata;  // LDS image of the tile and its look-behind
-    const uint8_t *dbm;    // digit bitmap of the image from bm_lo on, addressed by byte
+    const uint8_t *dbm;    // digit bitmap of the image from bm_lo on, addressed by byte (null: none kept)
     int bm_lo;
     bool has_nul, nulcut;
     const double *p10;
@@ -677,7 +703,7 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
             const uint32_t ty = (WRITE && convert) ? typed : (uint32_t)T_NONE;  // sizing needs lengths only
             uint64_t value = 0;
             bool valid = false;
-            if (len <= 16 && (int)s >= E.bm_lo) {
+            if (len <= 16 && (!E.dbm || (int)s >= E.bm_lo)) {
                 const uint4 w4 = lds_u128(sdata + s);
                 const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
                 const uint64_t hi = (uint64_t)w4.z | ((uint64_t)w4.w << 32);
@@ -688,10 +714,16 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
                     ehi = hi;
                     fast = true;
                 } else if (!cutting && ty != T_F32 && ty != T_BOOL) {
-                    const uint32_t boff = (uint32_t)((int)s - E.bm_lo);
-                    uint32_t dbits;
-                    __builtin_memcpy(&dbits, E.dbm + (boff >> 3), 4);
-                    fast = cell_fast(lo, hi, len, dbits >> (boff & 7), lvl, ty, E.p10, flen, value, valid, elo, ehi);
+                    uint32_t D16;
+                    if (E.dbm) {
+                        const uint32_t boff = (uint32_t)((int)s - E.bm_lo);
+                        uint32_t dbits;
+                        __builtin_memcpy(&dbits, E.dbm + (boff >> 3), 4);
+                        D16 = dbits >> (boff & 7);
+                    } else {  // no bitmap kept: classify the sixteen bytes here
+                        D16 = digit_mask16(w4);
+                    }
+                    fast = cell_fast(lo, hi, len, D16, lvl, ty, E.p10, flen, value, valid, elo, ehi);
                 }
                 if (!fast) flen = cell_scan16<false>(lo, hi, len, lvl, E.nulcut, ty, E.p10, nullptr, value, valid);
             } else if (len <= 16) {
@@ -1046,10 +1078,30 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                     }
                 }
                 __syncthreads();
+                STAMP(6);  // event list
                 const uint32_t cnt = nev_tile - w0 < EVCAP ? nev_tile - w0 : EVCAP;
-                for (uint32_t e = tid; e < cnt; e += BLOCK) {
-                    const uint32_t q = evpos[e], rl = evrank[e];
-                    if (rl != 0xFFu) match_tag(sdata, H, cols, ht, q, evt, rl, RB);
+                // three events per lane and turn, step by step: their LDS latencies overlap
+                constexpr int EVU = 3;
+                for (uint32_t e = tid; e < cnt; e += EVU * BLOCK) {
+                    uint32_t q[EVU], rl[EVU], slot[EVU];
+                    TagKey k[EVU];
+                    uint4 e0[EVU];
+#pragma unroll
+                    for (int u = 0; u < EVU; ++u) {
+                        const uint32_t ee = e + u * BLOCK;
+                        q[u] = ee < cnt ? evpos[ee] : 0u;
+                        rl[u] = ee < cnt ? evrank[ee] : 0xFFu;
+                    }
+#pragma unroll
+                    for (int u = 0; u < EVU; ++u) k[u] = tag_key(sdata, q[u]);
+#pragma unroll
+                    for (int u = 0; u < EVU; ++u) {
+                        slot[u] = tag_slot(H, k[u]);
+                        e0[u] = *(const uint4 *)&ht[slot[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < EVU; ++u)
+                        if (rl[u] != 0xFFu) tag_apply(sdata, cols, ht, q[u], k[u], slot[u], e0[u], evt, rl[u], RB);
                 }
                 __syncthreads();
             }
@@ -1285,14 +1337,13 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
 // search.  A block loads its tile (and the head of its first record from the look-behind),
 // rebuilds the digit bitmap, reads each cell's source from the map and runs the same column
 // routine as the tile kernel.  Tiles without a map are left to tile_kernel<true>.
-__global__ __launch_bounds__(BLOCK) void emit_kernel(const TileParams P) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void emit_kernel(const TileParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     const LdsLayout &L = P.L;
     uint8_t *sdata = smem + L.data;
     uint32_t *vmask = (uint32_t *)(smem + L.vmask);
     uint32_t *fmask = (uint32_t *)(smem + L.fmask);
     uint8_t *stage = smem + L.evlist;
-    uint64_t *dbm = (uint64_t *)(smem + L.dbm);
     uint32_t *mapl = (uint32_t *)(smem + L.evt);  // the batch's slice of the cell map: word (c, r) at c * RB + r
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: scalar loads for per-column data)
@@ -1333,10 +1384,15 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(const TileParams P) {
         ((uint4 *)sdata)[j] = j * CHUNK < te_li ? load_chunk(j) : make_uint4(0, 0, 0, 0);
     }
     for (int j = s0_li / CHUNK + tid; j < ts_li / CHUNK; j += BLOCK) ((uint4 *)sdata)[j] = load_chunk(j);
+    // of the schema only the header, the columns and the powers of ten (the tag table stays out)
+    const uint32_t sch_head = (uint32_t)sizeof(SchemaHdr) + ((ncols * (uint32_t)sizeof(DevCol) + 15) & ~15u);
     {
         const uint4 *g = (const uint4 *)P.schema;
         uint4 *s = (uint4 *)(smem + L.schema);
-        for (uint32_t i = tid; i < P.schema_bytes / 16; i += BLOCK) s[i] = g[i];
+        for (uint32_t i = tid; i < sch_head / 16; i += BLOCK) s[i] = g[i];
+        const uint64_t *gp = (const uint64_t *)(P.schema + Hg->p10_off);
+        uint64_t *sp = (uint64_t *)(smem + L.schema + sch_head);
+        if (tid < 23) sp[tid] = gp[tid];
     }
     uint32_t *tiletot = (uint32_t *)(smem + L.coltot);
     ColOut *colout = (ColOut *)(smem + L.colout);
@@ -1363,27 +1419,13 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(const TileParams P) {
     __syncthreads();
     const SchemaHdr *H = (const SchemaHdr *)(smem + L.schema);
     const DevCol *cols = (const DevCol *)(H + 1);
-    {
-        // digit bitmap of the tile and of the first look-behind window (bits of bytes in front
-        // of the first record come from stale LDS and are never looked at)
-        uint4 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = ((const uint4 *)sdata)[(ts_li + tid * 64) / CHUNK + k];
-        dbm[LB_FIRST / 64 + tid] = digit_mask64(v);
-        if (tile_start > 0 && tid < LB_FIRST / 64) {
-            uint4 u[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) u[k] = ((const uint4 *)sdata)[(bm_lo + tid * 64) / CHUNK + k];
-            dbm[tid] = digit_mask64(u);
-        }
-    }
     CellEnv E;
     E.sdata = sdata;
-    E.dbm = (const uint8_t *)dbm;
+    E.dbm = nullptr;  // digits are classified per cell: the bitmap's LDS buys a fifth block per CU instead
     E.bm_lo = bm_lo;
     E.has_nul = has_nul;
     E.nulcut = H->carry != 0 && H->mode != MODE_CSV;
-    E.p10 = (const double *)(smem + L.schema + H->p10_off);
+    E.p10 = (const double *)(smem + L.schema + sch_head);
     E.W = W;
     E.vmask = vmask;
     E.wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
@@ -1564,7 +1606,11 @@ hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream) {
     if (P.ntiles == 0) return hipSuccess;
     hipError_t e = hipFuncSetAttribute((const void *)emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(emit_kernel, dim3(P.ntiles), dim3(BLOCK), P.L.total, stream, P);
+    uint32_t lds = P.L.total;
+#ifdef MDC_ABLATE
+    if (const char *e = getenv("MDC_DEBUG_LDS")) lds = (uint32_t)atoi(e);  // occupancy experiments
+#endif
+    hipLaunchKernelGGL(emit_kernel, dim3(P.ntiles), dim3(BLOCK), lds, stream, P);
     return hipGetLastError();
 }
 
@@ -1574,10 +1620,14 @@ hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t strea
     const void *fn = write ? (const void *)tile_kernel<true> : (const void *)tile_kernel<false>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    uint32_t lds = P.L.total;
+#ifdef MDC_ABLATE
+    if (const char *e = getenv("MDC_DEBUG_LDS")) lds = (uint32_t)atoi(e);  // occupancy experiments
+#endif
     if (write)
-        hipLaunchKernelGGL(tile_kernel<true>, dim3(P.ntiles), dim3(BLOCK), P.L.total, stream, P);
+        hipLaunchKernelGGL(tile_kernel<true>, dim3(P.ntiles), dim3(BLOCK), lds, stream, P);
     else
-        hipLaunchKernelGGL(tile_kernel<false>, dim3(P.ntiles), dim3(BLOCK), P.L.total, stream, P);
+        hipLaunchKernelGGL(tile_kernel<false>, dim3(P.ntiles), dim3(BLOCK), lds, stream, P);
     return hipGetLastError();
 }
 

@@ -25,8 +25,8 @@ p.parse_device(d.ptr, d.n).free()
 L.mdc_debug_phase_counters(p.h, buf, 24, 1)
 p.parse_device(d.ptr, d.n).free()
 L.mdc_debug_phase_counters(p.h, buf, 24, 1)
-names = ["load+lookbehind", "terminators+rank", "clears", "events", "record->desc", "measure+convert",
-         "column scans", "stage bases", "cell copy", "copy-out+rows"]
+names = ["load+lookbehind", "classify+rank+s0", "clears+recend", "tag matching", "delimited desc", "cells (columns)",
+         "event list", "-", "-", "row outputs"]
 t = p.timing()
 print(f"rows={rows} count_ms={t.count_ms:.3f} write_ms={t.write_ms:.3f}")
 for label, base in (("count pass", 0), ("write pass", 12)):
