@@ -162,7 +162,7 @@ struct mdc_parser {
     uint32_t *d_status = nullptr;
     uint32_t *d_hdr = nullptr;      // per tile: cell map slot, first record start
     uint32_t *d_cellmap = nullptr;  // (ncols + 1) x map_cap words
-    size_t map_cap = 0;
+    size_t map_cap = 0, map_stride = 0;
     double rows_per_byte = 0;       // of the previous parse; sizes the cell map
     size_t ws_tiles = 0;
     uint64_t *h_totals = nullptr;  // pinned: ncols+1 totals + status
@@ -198,6 +198,9 @@ struct mdc_batch {
 
 static uint32_t round16(uint32_t v) { return (v + 15) & ~15u; }
 
+// five blocks per CU fit when a block asks for at most this much LDS (measured: 31.6 KB does, 32.2 KB does not)
+static const uint32_t LDS_FIVE_BLOCKS = 31 * 1024 + 256;
+
 static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32_t blob_bytes, uint32_t lbmax,
                            LdsLayout &L) {
     uint32_t RB = 112;
@@ -207,11 +210,12 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         L.data = o;
         o += round16(TILE + lbmax + DATA_SLACK);
         L.evlist = o;
-        L.evcap = 2048;
+        L.evcap = npat ? 1280 : 2048;  // tag events come in windows; the separators of a tile are kept all at once
         L.stage_cap = L.evcap * 3;
         o += L.evcap * 3;
         L.evt = o;
-        o += round16(RB * (npat > ncols + 2 ? npat : ncols + 2) * 4);
+        // XML: two 16-bit first positions per word; delimited: one descriptor word per field, plus the separator index
+        o += round16(npat ? (RB * npat + 1) / 2 * 4 : RB * (ncols + 2) * 4);
         L.recend = o;
         o += round16((RB + 1) * 4);
         L.vmask = o;
@@ -222,15 +226,13 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         o += round16(2 * (ncols + 1) * 4);
         L.colout = o;
         o += round16(ncols * 32);
-        L.dbm = o;
-        o += round16((LB_FIRST / 64 + BLOCK + 1) * 8);
         L.schema = o;
         o += round16(blob_bytes);
         L.misc = o;
         o += 64;
         L.total = o;
         L.RB = RB;
-        if (o <= 40 * 1024 || RB <= 8) break;
+        if (o <= LDS_FIVE_BLOCKS || RB <= 8) break;
         if (RB > 64 && lbmax > 1536) break;  // the larger look-behind configurations trade occupancy
         RB = RB > 16 ? RB - 8 : RB / 2;
     }
@@ -264,7 +266,7 @@ static void compute_emit_layout(uint32_t ncols, uint32_t words, uint32_t lbmax, 
         o += (uint32_t)sizeof(SchemaHdr) + round16(ncols * (uint32_t)sizeof(DevCol)) + 192;  // header, columns, 10^k
         L.total = o;
         L.RB = RB;
-        if (o <= 32 * 1024 || RB <= 8) break;
+        if (o <= LDS_FIVE_BLOCKS || RB <= 8) break;
         if (RB > 64 && lbmax > 1536) break;
         RB = RB > 16 ? RB - 8 : RB / 2;
     }
@@ -564,14 +566,24 @@ static int ensure_workspace(mdc_parser *p, size_t ntiles) {
     return MDC_OK;
 }
 
-// Room for the cell map: one word per column and record, plus the record ends.  The number of
-// records is not known before the sizing pass, so the capacity is a guess (the previous
-// parse's records per byte with a margin, else one record per 32 bytes); tiles that find no
-// room are written by the full write kernel instead.  The allocation counter sits behind it.
-static int ensure_cellmap(mdc_parser *p, size_t n) {
-    double rpb = p->rows_per_byte > 0 ? p->rows_per_byte * 1.125 : 1.0 / 32;
-    size_t want = (size_t)((double)n * rpb) + 4096;
-    if (want > 0xFFFF0000u) want = 0xFFFF0000u;
+// Room for the cell map: every tile owns map_stride record slots (one word per column and
+// record, plus the record ends).  The number of records per tile is not known before the
+// sizing pass, so the stride is a guess: the previous parse's records per tile with a margin,
+// else one record per 32 bytes; a tile with more records than that is written by the full
+// write kernel instead.
+static int ensure_cellmap(mdc_parser *p, size_t n, size_t ntiles) {
+    size_t stride = TILE / 32;
+    if (p->rows_per_byte > 0) {
+        stride = (size_t)(p->rows_per_byte * TILE * 1.25) + 16;
+        stride = (stride + 15) & ~(size_t)15;
+    }
+    p->map_stride = stride;
+    size_t want = stride * (ntiles ? ntiles : 1);
+    (void)n;
+    if (want > 0xFFFF0000u) {  // beyond 32-bit slot numbers: no map, every tile takes the full write kernel
+        p->map_stride = 0;
+        return MDC_OK;
+    }
     if (p->d_cellmap && want <= p->map_cap && p->map_cap <= 4 * want) return MDC_OK;
     dev_free(p->dev, p->d_cellmap);
     p->d_cellmap = nullptr;
@@ -604,7 +616,7 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     const size_t ntiles = (n + TILE - 1) / TILE;
     int rc = ensure_workspace(p, ntiles ? ntiles : 1);
     if (rc) return rc;
-    rc = ensure_cellmap(p, n);
+    rc = ensure_cellmap(p, n, ntiles);
     if (rc) return rc;
 
     TileParams P{};
@@ -616,9 +628,9 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     P.tile_counts = p->d_counts;
     P.tile_base = p->d_base;
     P.status = p->d_status;
-    P.cellmap = p->d_cellmap;
+    P.cellmap = p->map_stride ? p->d_cellmap : nullptr;
     P.map_cap = (uint32_t)p->map_cap;
-    P.map_alloc = p->d_cellmap + ((size_t)p->ncols + 1) * p->map_cap;
+    P.map_stride = (uint32_t)p->map_stride;
     P.tile_hdr = p->d_hdr;
 #ifdef MDC_ABLATE
     if (const char *dbg = getenv("MDC_DEBUG_SKIP")) P.debug = (uint32_t)atoi(dbg);
@@ -631,7 +643,6 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     for (;;) {
         P.L = p->Ls[p->lb_level];
         HIP_TRY(hipMemsetAsync(p->d_status, 0, 4, s));
-        HIP_TRY(hipMemsetAsync(P.map_alloc, 0, 4, s));
         HIP_TRY(hipEventRecord(p->ev[0], s));
         HIP_TRY(launch_tile_kernel(false, P, s));
         HIP_TRY(hipEventRecord(p->ev[1], s));

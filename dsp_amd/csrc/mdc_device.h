@@ -89,14 +89,13 @@ static_assert(sizeof(SchemaHdr) % 16 == 0, "SchemaHdr must keep 16-byte alignmen
 struct LdsLayout {
     uint32_t data;    // TILE+LBMAX+DATA_SLACK bytes
     uint32_t evlist;  // evcap x (u16 position + u8 batch rank) of the '<' events; later the cell staging area
-    uint32_t evt;     // RB*max(npat,ncols) u32: first position of every tag pattern per record
+    uint32_t evt;     // RB*npat u16: first position of every tag pattern per record
                       // (delimited mode: the field descriptors)
     uint32_t recend;  // (RB+1) u32
     uint32_t vmask;   // RB*words u32
     uint32_t fmask;   // RB*words u32
     uint32_t coltot;  // 2*(ncols+1) u32: batch totals, tile totals
     uint32_t colout;  // ncols x 32 bytes: output pointers and tile base of every column
-    uint32_t dbm;     // (LB_FIRST/64 + BLOCK + 1) u64: digit bitmap of the tile and the first look-behind window
     uint32_t schema;  // schema blob
     uint32_t misc;    // block-wide scalars
     uint32_t total;
@@ -129,8 +128,8 @@ struct TileParams {
     // neither the tag search nor the record split again.  Column-major: word (c, slot + r) at
     // cellmap[c * map_cap + slot + r], c == ncols holds the record ends.
     uint32_t *cellmap;
-    uint32_t map_cap;            // records the map has room for
-    uint32_t *map_alloc;         // next free slot (bump allocation, one atomic per tile)
+    uint32_t map_cap;            // record slots of the map = ntiles * map_stride
+    uint32_t map_stride;         // record slots per tile: tile t owns [t * map_stride, (t + 1) * map_stride)
     uint32_t *tile_hdr;          // [ntiles][2]: slot (NONE = not mapped), first record start | has_nul << 31
     uint32_t only_unmapped;      // write kernel: leave the mapped tiles to the emit kernel
     uint32_t debug;  // diagnostic builds only: phases to skip (ablation timing)

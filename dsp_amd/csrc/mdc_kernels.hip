@@ -171,7 +171,6 @@ enum {
     MS_STAGED = 2,
     MS_LBCNT = 3,   // events found in the look-behind region
     MS_WTOT = 4,    // 4 words: per-wave totals of the rank/event scan
-    MS_SLOT = 8,    // sizing pass: the tile's first slot in the cell map (NONE = no room)
     MS_NOMAP = 9,   // sizing pass: a cell does not fit a map word
     MS_COUNT = 16
 };
@@ -227,6 +226,27 @@ __device__ __forceinline__ bool is_term(const uint8_t *sdata, const SchemaHdr *H
     return true;
 }
 
+// first_pos[pattern][record] is kept in 16 bits (positions in the LDS image are below 2^15), two
+// entries per LDS word; LDS atomics are 32 bits wide, so the minimum is taken with a
+// compare-and-swap on the word (two events rarely meet in one word: one round, as a rule)
+constexpr uint32_t NONE16 = 0xFFFFu;
+__device__ __forceinline__ void evt_min(uint32_t *evt, uint32_t idx, uint32_t q) {
+    uint32_t *w = evt + (idx >> 1);
+    const uint32_t sh = (idx & 1) * 16;
+    uint32_t old = 0xFFFFFFFFu;  // guess: untouched (a wrong guess costs one round and returns the truth)
+    for (;;) {
+        if (((old >> sh) & 0xFFFFu) <= q) return;
+        const uint32_t want = (old & ~(0xFFFFu << sh)) | (q << sh);
+        const uint32_t seen = atomicCAS(w, old, want);
+        if (seen == old) return;
+        old = seen;
+    }
+}
+__device__ __forceinline__ uint32_t evt_get(const uint32_t *evt, uint32_t idx) {
+    const uint32_t v = ((const uint16_t *)evt)[idx];
+    return v == NONE16 ? NONE : v;
+}
+
 // Tag lookup for the '<' at LDS index q, in three steps so that a lane can keep several events
 // in flight (every step starts with an LDS access whose latency the others hide):
 //   tag_key    one unaligned 8-byte read: the key = text up to and including '>' (at most 8 bytes)
@@ -279,7 +299,7 @@ __device__ __forceinline__ void tag_apply(const uint8_t *sdata, const DevCol *co
                 if (ok && sdata[a + tlen] != '>') ok = false;
             }
         }
-        if (ok) atomicMin(&evt[(2 * col + kind) * RB + rl], q);
+        if (ok) evt_min(evt, (2 * col + kind) * RB + rl, q);
         slot = e.next;
         if (!slot) break;
     }
@@ -434,8 +454,7 @@ __device__ __forceinline__ uint32_t cell_scan16(uint64_t lo, uint64_t hi, uint32
 }
 
 // ---------------------------------------------------------------------------------------
-// Fast cell path.  A 64-bit digit bitmap per 64 tile bytes (made with the other SWAR masks
-// during classification) tells, for any cell of up to 16 source bytes, which bytes are
+// Fast cell path.  For a cell of up to 16 source bytes a 16-bit mask says which bytes are
 // digits.  Cells with at most two other bytes (a sign, a decimal point, one stray byte: all
 // well-formed numbers and dates) are measured, filtered and converted without any per-byte
 // loop; everything else takes cell_scan16 / cell_filter_long.
@@ -452,13 +471,6 @@ __device__ __forceinline__ uint32_t digit_mask16(const uint4 &v) {
     const uint32_t a1 = __builtin_amdgcn_udot4(digit_flags(v.w), 0x80402010u,
                                                __builtin_amdgcn_udot4(digit_flags(v.z), 0x08040201u, 0u, false), false);
     return (a0 >> 7) | (a1 << 1);
-}
-__device__ __forceinline__ uint64_t digit_mask64(const uint4 (&v)[4]) {
-    const uint32_t lo = pack32(digit_flags(v[0].x), digit_flags(v[0].y), digit_flags(v[0].z), digit_flags(v[0].w),
-                               digit_flags(v[1].x), digit_flags(v[1].y), digit_flags(v[1].z), digit_flags(v[1].w));
-    const uint32_t hi = pack32(digit_flags(v[2].x), digit_flags(v[2].y), digit_flags(v[2].z), digit_flags(v[2].w),
-                               digit_flags(v[3].x), digit_flags(v[3].y), digit_flags(v[3].z), digit_flags(v[3].w));
-    return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
 // byte p (0..15) of the 16-byte window (lo, hi)
@@ -645,8 +657,6 @@ __device__ __forceinline__ uint32_t map_pack(uint32_t start, uint32_t len, uint3
 // what a wave needs, besides the cells' sources, to turn one column of a batch into output
 struct CellEnv {
     const uint8_t *sdata;  // LDS image of the tile and its look-behind
-    const uint8_t *dbm;    // digit bitmap of the image from bm_lo on, addressed by byte (null: none kept)
-    int bm_lo;
     bool has_nul, nulcut;
     const double *p10;
     uint32_t W;
@@ -703,7 +713,7 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
             const uint32_t ty = (WRITE && convert) ? typed : (uint32_t)T_NONE;  // sizing needs lengths only
             uint64_t value = 0;
             bool valid = false;
-            if (len <= 16 && (!E.dbm || (int)s >= E.bm_lo)) {
+            if (len <= 16) {
                 const uint4 w4 = lds_u128(sdata + s);
                 const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
                 const uint64_t hi = (uint64_t)w4.z | ((uint64_t)w4.w << 32);
@@ -714,22 +724,9 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
                     ehi = hi;
                     fast = true;
                 } else if (!cutting && ty != T_F32 && ty != T_BOOL) {
-                    uint32_t D16;
-                    if (E.dbm) {
-                        const uint32_t boff = (uint32_t)((int)s - E.bm_lo);
-                        uint32_t dbits;
-                        __builtin_memcpy(&dbits, E.dbm + (boff >> 3), 4);
-                        D16 = dbits >> (boff & 7);
-                    } else {  // no bitmap kept: classify the sixteen bytes here
-                        D16 = digit_mask16(w4);
-                    }
-                    fast = cell_fast(lo, hi, len, D16, lvl, ty, E.p10, flen, value, valid, elo, ehi);
+                    fast = cell_fast(lo, hi, len, digit_mask16(w4), lvl, ty, E.p10, flen, value, valid, elo, ehi);
                 }
                 if (!fast) flen = cell_scan16<false>(lo, hi, len, lvl, E.nulcut, ty, E.p10, nullptr, value, valid);
-            } else if (len <= 16) {
-                const uint4 w4 = lds_u128(sdata + s);
-                flen = cell_scan16<false>((uint64_t)w4.x | ((uint64_t)w4.y << 32), (uint64_t)w4.z | ((uint64_t)w4.w << 32),
-                                          len, lvl, E.nulcut, ty, E.p10, nullptr, value, valid);
             } else {
                 flen = cell_filter_long<false>(sdata + s, len, lvl, E.nulcut, nullptr);
                 if (ty != T_NONE) deferred = true;  // value and valid bit come from the second stage
@@ -813,7 +810,6 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     uint32_t *fmask = (uint32_t *)(smem + L.fmask);
     uint8_t *stage = smem + L.evlist;  // the event list is dead when cells are staged
     uint32_t *ms = (uint32_t *)(smem + L.misc);
-    uint64_t *dbm = (uint64_t *)(smem + L.dbm);  // digit bitmap: bit (li - bm_lo) of the LDS image
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: scalar loads for per-column data)
@@ -828,7 +824,6 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     const int ts_li = LB;
     const int te_li = LB + (int)(tile_end - tile_start);
     const int li_min = base_pos < 0 ? (int)(-base_pos) : 0;
-    const int bm_lo = ts_li - LB_FIRST;  // first LDS index covered by the digit bitmap
 
     auto load_chunk = [&](int j) -> uint4 {  // 16-byte chunk j of the LDS image, from global memory
         const int64_t pos = base_pos + (int64_t)j * CHUNK;
@@ -911,13 +906,6 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         uint64_t nlm = mask64_eq(v, 0x0A0A0A0Au);
         em = !csv ? mask64_eq(v, 0x3C3C3C3Cu) : sepfast ? mask64_eq(v, rep4(H->sep[0])) : 0;
         if (any_zero64(v)) ms[MS_HASNUL] = 1;
-        dbm[LB_FIRST / 64 + tid] = digit_mask64(v);
-        if (tile_start > 0 && tid < LB_FIRST / 64) {  // and for the first look-behind window
-            uint4 u[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) u[k] = ((const uint4 *)sdata)[(bm_lo + tid * 64) / CHUNK + k];
-            dbm[tid] = digit_mask64(u);
-        }
         const int lim = te_li - my_li;  // bytes of this lane that belong to the input
         if (lim < 64) {
             const uint64_t keep = lim <= 0 ? 0 : (~0ull >> (64 - lim));
@@ -977,15 +965,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         }
     }
     const bool has_nul = ms[MS_HASNUL] != 0;
-    if (!WRITE && tid == 0) {
-        // room for this tile's records in the cell map (read after the next barrier)
-        uint32_t slot = NONE;
-        if (P.cellmap && nrec) {
-            slot = atomicAdd(P.map_alloc, nrec);
-            if (slot > P.map_cap || nrec > P.map_cap - slot) slot = NONE;
-        }
-        ms[MS_SLOT] = slot;
-    }
+    // the tile's place in the cell map: map_stride record slots per tile, no allocation needed
+    const uint32_t map_slot = (!WRITE && P.cellmap && nrec <= P.map_stride) ? blockIdx.x * P.map_stride : NONE;
     const uint32_t RB = L.RB, EVCAP = L.evcap;
     const uint64_t *tb = WRITE ? P.tile_base + (uint64_t)blockIdx.x * (ncols + 1) : nullptr;
     const uint64_t row0 = WRITE ? tb[ncols] : 0;
@@ -1024,7 +1005,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     // ---- batches of RB records
     for (uint32_t rb0 = 0; rb0 < nrec; rb0 += RB) {
         const uint32_t RBn = (nrec - rb0 < RB) ? nrec - rb0 : RB;
-        for (uint32_t i = tid; i < RB * npat; i += BLOCK) evt[i] = NONE;
+        for (uint32_t i = tid; i < (RB * npat + 1) / 2; i += BLOCK) evt[i] = NONE;
         for (uint32_t i = tid; i < RB * W; i += BLOCK) {
             vmask[i] = 0;
             fmask[i] = 0;
@@ -1215,8 +1196,6 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         bool deferred = false;
         CellEnv E;
         E.sdata = sdata;
-        E.dbm = (const uint8_t *)dbm;
-        E.bm_lo = bm_lo;
         E.has_nul = has_nul;
         E.nulcut = nulcut;
         E.p10 = p10;
@@ -1224,7 +1203,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         E.vmask = vmask;
         E.wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
         E.wstage_cap = L.stage_cap / (BLOCK / 64);
-        const uint32_t slot = WRITE ? NONE : ms[MS_SLOT];
+        const uint32_t slot = map_slot;
         const bool mapping = !WRITE && slot != NONE;
         for (uint32_t c = wave; c < ncols && !SKIP(2); c += BLOCK / 64) {
             const uint32_t typed = cols[c].typed;
@@ -1248,7 +1227,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                         // splitbuffer's carry-forward: a missing tag keeps the nearest earlier
                         // column's value, filtered by every column in between
                         const uint32_t re = recend[r + 1];
-                        uint32_t o = evt[(2 * c) * RB + r], e = evt[(2 * c + 1) * RB + r];
+                        uint32_t o = evt_get(evt, (2 * c) * RB + r), e = evt_get(evt, (2 * c + 1) * RB + r);
                         found = (o != NONE) & (e != NONE);
                         uint32_t cs = c;
                         lvl = clvl;
@@ -1256,8 +1235,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                         if (!found && carry) {
                             while (cs > 0) {
                                 --cs;
-                                o = evt[(2 * cs) * RB + r];
-                                e = evt[(2 * cs + 1) * RB + r];
+                                o = evt_get(evt, (2 * cs) * RB + r);
+                                e = evt_get(evt, (2 * cs + 1) * RB + r);
                                 const uint32_t l2 = cols[cs].level;
                                 if (l2 > lvl) lvl = l2;
                                 if ((o != NONE) & (e != NONE)) {
@@ -1323,7 +1302,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             tc[ncols] = nrec;
             if (P.tile_hdr) {
                 // all batches are done (the loop ends with a barrier): is the tile's map complete?
-                const uint32_t slot = nrec ? ms[MS_SLOT] : 0u;
+                const uint32_t slot = map_slot;
                 const bool mapped = slot != NONE && !ms[MS_NOMAP];
                 P.tile_hdr[2 * blockIdx.x] = mapped ? slot : NONE;
                 P.tile_hdr[2 * blockIdx.x + 1] = (uint32_t)s0_li | (has_nul ? 0x80000000u : 0u);
@@ -1368,7 +1347,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     const int64_t base_pos = tile_start - LB;
     const int ts_li = LB;
     const int te_li = LB + (int)(tile_end - tile_start);
-    const int bm_lo = ts_li - LB_FIRST;
 
     auto load_chunk = [&](int j) -> uint4 {
         const int64_t pos = base_pos + (int64_t)j * CHUNK;
@@ -1421,8 +1399,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     const DevCol *cols = (const DevCol *)(H + 1);
     CellEnv E;
     E.sdata = sdata;
-    E.dbm = nullptr;  // digits are classified per cell: the bitmap's LDS buys a fifth block per CU instead
-    E.bm_lo = bm_lo;
     E.has_nul = has_nul;
     E.nulcut = H->carry != 0 && H->mode != MODE_CSV;
     E.p10 = (const double *)(smem + L.schema + sch_head);
