@@ -572,25 +572,31 @@ static int ensure_workspace(mdc_parser *p, size_t ntiles) {
 // else one record per 32 bytes; a tile with more records than that is written by the full
 // write kernel instead.
 static int ensure_cellmap(mdc_parser *p, size_t n, size_t ntiles) {
+    const size_t per_slot = ((size_t)p->ncols + 1) * 4;
     size_t stride = TILE / 32;
     if (p->rows_per_byte > 0) {
         stride = (size_t)(p->rows_per_byte * TILE * 1.25) + 16;
         stride = (stride + 15) & ~(size_t)15;
     }
-    p->map_stride = stride;
-    size_t want = stride * (ntiles ? ntiles : 1);
-    (void)n;
-    if (want > 0xFFFF0000u) {  // beyond 32-bit slot numbers: no map, every tile takes the full write kernel
+    if (ntiles == 0) ntiles = 1;
+    // the map is scratch: keep it within twice the input (64 MiB at least)
+    const size_t budget = n > ((size_t)32 << 20) ? 2 * n : (size_t)64 << 20;
+    if (stride * ntiles * per_slot > budget) stride = (budget / (ntiles * per_slot)) & ~(size_t)15;
+    size_t want = stride * ntiles;
+    if (stride == 0 || want > 0xFFFF0000u) {  // no map: every tile takes the full write kernel
         p->map_stride = 0;
         return MDC_OK;
     }
+    p->map_stride = stride;
     if (p->d_cellmap && want <= p->map_cap && p->map_cap <= 4 * want) return MDC_OK;
     dev_free(p->dev, p->d_cellmap);
     p->d_cellmap = nullptr;
     p->map_cap = 0;
     void *m = nullptr;
-    int rc = dev_alloc(p->dev, ((size_t)p->ncols + 1) * want * 4 + 64, &m);
-    if (rc) return rc;
+    if (dev_alloc(p->dev, per_slot * want + 64, &m) != MDC_OK) {
+        p->map_stride = 0;  // no memory to spare for the map: do without
+        return MDC_OK;
+    }
     p->d_cellmap = (uint32_t *)m;
     p->map_cap = want;
     return MDC_OK;
