@@ -1042,50 +1042,18 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                     }
                 }
             }
-            // ---- C/D. compact the tile's events into a dense list, then one lane per event
-            for (uint32_t w0 = 0; w0 < nev_tile; w0 += EVCAP) {
-                {
-                    uint64_t m = em;
-                    uint32_t idx = ev_base;
-                    while (m) {
-                        const int b = __builtin_ctzll(m);
-                        m &= m - 1;
-                        if (idx >= w0 && idx < w0 + EVCAP) {
-                            const uint32_t r = rank_base + (uint32_t)__builtin_popcountll(tm & ((1ull << b) - 1));
-                            evpos[idx - w0] = (uint16_t)(my_li + b);
-                            evrank[idx - w0] = (r >= rb0 && r < rb0 + RBn) ? (uint8_t)(r - rb0) : (uint8_t)0xFF;
-                        }
-                        ++idx;
-                    }
+            // ---- C/D. every lane looks up the tags of its own '<' bytes (no list, no barrier: a
+            // balanced event list costs more to build than the idle lanes it saves)
+            {
+                uint64_t m = em;
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t r = rank_base + (uint32_t)__builtin_popcountll(tm & ((1ull << b) - 1));
+                    if (r >= rb0 && r < rb0 + RBn) match_tag(sdata, H, cols, ht, (uint32_t)(my_li + b), evt, r - rb0, RB);
                 }
-                __syncthreads();
-                STAMP(6);  // event list
-                const uint32_t cnt = nev_tile - w0 < EVCAP ? nev_tile - w0 : EVCAP;
-                // three events per lane and turn, step by step: their LDS latencies overlap
-                constexpr int EVU = 3;
-                for (uint32_t e = tid; e < cnt; e += EVU * BLOCK) {
-                    uint32_t q[EVU], rl[EVU], slot[EVU];
-                    TagKey k[EVU];
-                    uint4 e0[EVU];
-#pragma unroll
-                    for (int u = 0; u < EVU; ++u) {
-                        const uint32_t ee = e + u * BLOCK;
-                        q[u] = ee < cnt ? evpos[ee] : 0u;
-                        rl[u] = ee < cnt ? evrank[ee] : 0xFFu;
-                    }
-#pragma unroll
-                    for (int u = 0; u < EVU; ++u) k[u] = tag_key(sdata, q[u]);
-#pragma unroll
-                    for (int u = 0; u < EVU; ++u) {
-                        slot[u] = tag_slot(H, k[u]);
-                        e0[u] = *(const uint4 *)&ht[slot[u]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < EVU; ++u)
-                        if (rl[u] != 0xFFu) tag_apply(sdata, cols, ht, q[u], k[u], slot[u], e0[u], evt, rl[u], RB);
-                }
-                __syncthreads();
             }
+            __syncthreads();
         }
         STAMP(3);  // events
 
