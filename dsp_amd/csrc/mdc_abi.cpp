@@ -155,6 +155,7 @@ struct mdc_parser {
     void *d_blob = nullptr;
     LdsLayout Ls[3]{};  // one layout per look-behind level
     LdsLayout LEs[3]{}; // ... and the emit kernel's
+    LdsLayout LSs[3]{}; // ... and the sizing pass's
     int lb_level = 0;   // level that fitted the previous parse
     // workspace
     uint32_t *d_counts = nullptr;
@@ -201,8 +202,11 @@ static uint32_t round16(uint32_t v) { return (v + 15) & ~15u; }
 // five blocks per CU fit when a block asks for at most this much LDS (measured: 31.6 KB does, 32.2 KB does not)
 static const uint32_t LDS_FIVE_BLOCKS = 31 * 1024 + 256;
 
+// lean = the sizing pass of tagged input: it keeps no event list, stages no cells and needs no
+// output pointers, which is worth a sixth block per CU
+static const uint32_t LDS_SIX_BLOCKS = 25 * 1024 + 512;
 static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32_t blob_bytes, uint32_t lbmax,
-                           LdsLayout &L) {
+                           LdsLayout &L, bool lean = false) {
     uint32_t RB = 112;
     for (;;) {
         uint32_t o = 0;
@@ -210,7 +214,7 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         L.data = o;
         o += round16(TILE + lbmax + DATA_SLACK);
         L.evlist = o;
-        L.evcap = npat ? 1280 : 2048;  // tag events come in windows; the separators of a tile are kept all at once
+        L.evcap = lean ? 0 : npat ? 1280 : 2048;  // staging area of the full write kernel; separators of a tile
         L.stage_cap = L.evcap * 3;
         o += L.evcap * 3;
         L.evt = o;
@@ -225,14 +229,14 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         L.coltot = o;
         o += round16(2 * (ncols + 1) * 4);
         L.colout = o;
-        o += round16(ncols * 32);
+        if (!lean) o += round16(ncols * 32);
         L.schema = o;
         o += round16(blob_bytes);
         L.misc = o;
         o += 64;
         L.total = o;
         L.RB = RB;
-        if (o <= LDS_FIVE_BLOCKS || RB <= 8) break;
+        if (o <= (lean ? LDS_SIX_BLOCKS : LDS_FIVE_BLOCKS) || RB <= 8) break;
         if (RB > 64 && lbmax > 1536) break;  // the larger look-behind configurations trade occupancy
         RB = RB > 16 ? RB - 8 : RB / 2;
     }
@@ -337,12 +341,14 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
             memcpy(&q.hi, key + 4, 4);
             pats.push_back(q);
         }
+    // the smallest table (a power of two, 1.4 slots per pattern at least) for which a seed
+    // exists: every 32-byte slot is LDS that the kernels would rather spend on resident blocks
     uint32_t ht_size = 16, seed = 0;
-    while (ht_size < 2 * npat) ht_size <<= 1;
+    while (ht_size * 5 < npat * 7) ht_size <<= 1;
     std::vector<int> head;  // slot -> first pattern index with that key, or -1
     for (;;) {
         bool ok = false;
-        for (seed = 0; seed < 4096 && !ok; ++seed) {
+        for (seed = 0; seed < 65536 && !ok; ++seed) {
             head.assign(ht_size, -1);
             ok = true;
             for (size_t i = 0; i < pats.size() && ok; ++i) {
@@ -424,6 +430,7 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
     for (int lv = 0; lv < 3; ++lv) {
         compute_layout(ncols, npat, p->words, (uint32_t)p->blob.size(), LB_LEVELS[lv], p->Ls[lv]);
         compute_emit_layout(ncols, p->words, LB_LEVELS[lv], p->LEs[lv]);
+        compute_layout(ncols, npat, p->words, (uint32_t)p->blob.size(), LB_LEVELS[lv], p->LSs[lv], npat != 0);
         if (p->Ls[lv].total > 160 * 1024)
             return fail(MDC_ERR_ARG, "schema too large for LDS (%u bytes)", p->Ls[lv].total);
     }
@@ -647,7 +654,7 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     // parse; a record that does not fit raises ST_RECORD_TOO_LONG and the pass is repeated
     // with the next larger capacity (which costs blocks per CU, so it is not the default).
     for (;;) {
-        P.L = p->Ls[p->lb_level];
+        P.L = p->LSs[p->lb_level];
         HIP_TRY(hipMemsetAsync(p->d_status, 0, 4, s));
         HIP_TRY(hipEventRecord(p->ev[0], s));
         HIP_TRY(launch_tile_kernel(false, P, s));

@@ -802,7 +802,6 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     const LdsLayout &L = P.L;
     uint8_t *sdata = smem + L.data;
     uint16_t *evpos = (uint16_t *)(smem + L.evlist);         // dense list of '<' events: LDS index
-    uint8_t *evrank = smem + L.evlist + 2 * L.evcap;         // ... and record rank within the batch
     uint32_t *evt = (uint32_t *)(smem + L.evt);
     uint32_t *desc = (uint32_t *)(smem + L.evt);  // delimited mode has no tag events: same space
     uint32_t *recend = (uint32_t *)(smem + L.recend);
