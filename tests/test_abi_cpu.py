@@ -66,3 +66,13 @@ def test_normalise_matches_reference_rules():
     for t in ("number", "integer", "float"):
         assert n("x", t, 5) == schema.Col("x", "number", 22)
     assert n("b", "blob", 4000) is None and n("t", "timestamp(6)", 11) is None
+
+
+def test_stream_entry_points_check_their_arguments():
+    import ctypes
+    L = capi.lib()
+    st = ctypes.c_void_p()
+    assert L.mdc_stream_open(None, None, 0, 1, ctypes.byref(st)) == capi.MDC_ERR_ARG
+    assert L.mdc_stream_next(None, None, None) == capi.MDC_ERR_ARG
+    assert L.mdc_stream_bytes(None) == 0
+    L.mdc_stream_close(None)  # a no-op
