@@ -388,3 +388,43 @@ def test_delimited_long_batch_with_trim(port, bdel):
     got = gpu_csv(data, ",", 6, typed=typed, bdelspace=bdel, ilen=[0, 5, 0, 3, 0, 0])
     exp = port.parse_csv(data, ",", 6, ilen=[0, 5, 0, 3, 0, 0], typed=typed, bdelspace=bdel)
     assert_batches_equal(got, exp, "delimited, many tiles")
+
+
+def test_full_size_batch_equals_its_parts(port):
+    """1 GiB (the size the metric is quoted on): the parse of the whole batch equals the
+    concatenation of the parses of four parts cut at record terminators, and the first part's
+    head equals the CPU checker; rows match the generator's count."""
+    from dsp_amd import shard
+
+    data, n = gen.mind_xml(nbytes=1 << 30)
+    p = capi.Parser.xml(schema.ZHOBTMIND)
+    whole_b = p.parse_host(data)
+    assert whole_b.rows == n
+    whole = whole_b.to_host()
+    whole_b.free()
+    row = 0
+    pos = [0] * whole.ncols
+    for lo, hi in shard.split_points(data, 4):
+        b = p.parse_host(data[lo:hi])
+        part = b.to_host()
+        b.free()
+        m = part.rows
+        assert np.array_equal(part.rec_off[1:] + np.uint64(lo), whole.rec_off[row + 1: row + m + 1])
+        assert np.array_equal(part.valid, whole.valid[row: row + m])
+        assert np.array_equal(part.found, whole.found[row: row + m])
+        for c in range(whole.ncols):
+            nb = int(part.off[c][m])
+            assert np.array_equal(part.off[c][1:].astype(np.uint64) + np.uint64(pos[c]),
+                                  whole.off[c][row + 1: row + m + 1].astype(np.uint64)), c
+            assert np.array_equal(part.data[c][:nb], whole.data[c][pos[c]: pos[c] + nb]), c
+            if whole.val[c] is not None and len(whole.val[c]):
+                assert np.array_equal(part.val[c][:m], whole.val[c][row: row + m]), c
+            pos[c] += nb
+        row += m
+    assert row == n
+    cut = int(np.flatnonzero(data[: 4 << 20] == 10)[-1]) + 1
+    exp = port.parse_xml(np.ascontiguousarray(data[:cut]), schema.ZHOBTMIND)
+    for c in range(exp.ncols):
+        assert np.array_equal(whole.off[c][: exp.rows + 1], exp.off[c])
+        assert np.array_equal(whole.data[c][: int(exp.off[c][exp.rows])], exp.data[c])
+    p.close()
