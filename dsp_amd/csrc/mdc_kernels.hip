@@ -1300,12 +1300,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         if (tid == 0 && P.rec_off) P.rec_off[0] = 0;
         for (uint32_t c = tid; c < ncols; c += BLOCK) P.off[c][0] = 0;
     }
-    const uint32_t slot = P.tile_hdr[2 * tile];
-    const uint32_t nrec = P.tile_counts[(uint64_t)tile * (ncols + 1) + ncols];
-    if (slot == NONE || nrec == 0) return;
+    // Everything the block needs is requested before anything is waited for: the tile's header
+    // words, the tile itself, the first look-behind window and the tile's slice of the cell map
+    // (whose place, tile * map_stride, does not depend on the header).
+    const uint32_t hslot = P.tile_hdr[2 * tile];
     const uint32_t hw = P.tile_hdr[2 * tile + 1];
-    const int s0_li = (int)(hw & 0x7FFFFFFFu);
-    const bool has_nul = (hw >> 31) != 0;
+    const uint32_t nrec = P.tile_counts[(uint64_t)tile * (ncols + 1) + ncols];
+    const uint32_t slot = tile * P.map_stride;
 
     const int64_t n = (int64_t)P.n;
     const int64_t tile_start = (int64_t)tile * TILE;
@@ -1323,12 +1324,28 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             if (pos + k < n) w[k >> 2] |= (uint32_t)P.data[pos + k] << (8 * (k & 3));
         return make_uint4(w[0], w[1], w[2], w[3]);
     };
+    uint4 tv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int j = ts_li / CHUNK + k * BLOCK + tid;
-        ((uint4 *)sdata)[j] = j * CHUNK < te_li ? load_chunk(j) : make_uint4(0, 0, 0, 0);
+        tv[k] = j * CHUNK < te_li ? load_chunk(j) : make_uint4(0, 0, 0, 0);
     }
-    for (int j = s0_li / CHUNK + tid; j < ts_li / CHUNK; j += BLOCK) ((uint4 *)sdata)[j] = load_chunk(j);
+    const int jw = (ts_li - LB_FIRST) / CHUNK + tid;  // this thread's chunk of the first look-behind window
+    const bool lbmine = tid < LB_FIRST / CHUNK && base_pos + (int64_t)jw * CHUNK >= 0;
+    uint4 lbv = make_uint4(0, 0, 0, 0);
+    if (lbmine) lbv = load_chunk(jw);
+    const uint32_t RB = L.RB;
+    const uint32_t RBs = P.map_stride < RB ? P.map_stride : RB;  // records of the first batch, at most
+    const uint32_t nwords = (ncols + 1) * RBs;
+    const uint32_t magic_s = 0xFFFFFFFFu / RBs + 1;  // i / RBs == umulhi(i, magic_s) for i < 2^15 (RBs >= 2)
+    constexpr int MAPREG = 8;
+    uint32_t mv[MAPREG];
+#pragma unroll
+    for (int k = 0; k < MAPREG; ++k) {
+        const uint32_t i = (uint32_t)k * BLOCK + tid;
+        const uint32_t c = RBs == 1 ? i : __umulhi(i, magic_s);
+        mv[k] = i < nwords ? P.cellmap[(uint64_t)c * P.map_cap + slot + (i - c * RBs)] : 0u;
+    }
     // of the schema only the header, the columns and the powers of ten (the tag table stays out)
     const uint32_t sch_head = (uint32_t)sizeof(SchemaHdr) + ((ncols * (uint32_t)sizeof(DevCol) + 15) & ~15u);
     {
@@ -1352,15 +1369,32 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         colout[c] = o;
     }
     const uint64_t row0 = tb[ncols];
-    const uint32_t RB = L.RB;
-    // the map words of a batch, fetched together with the tile so that their latency overlaps
+
+    if (hslot == NONE || nrec == 0) return;  // no map (the full write kernel has the tile), or nothing to write
+    const int s0_li = (int)(hw & 0x7FFFFFFFu);
+    const bool has_nul = (hw >> 31) != 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ((uint4 *)sdata)[ts_li / CHUNK + k * BLOCK + tid] = tv[k];
+    if (lbmine) ((uint4 *)sdata)[jw] = lbv;
+    // (rare) the first record starts in front of the first look-behind window
+    for (int j = s0_li / CHUNK + tid; j < (ts_li - LB_FIRST) / CHUNK; j += BLOCK) ((uint4 *)sdata)[j] = load_chunk(j);
+#pragma unroll
+    for (int k = 0; k < MAPREG; ++k) {
+        const uint32_t i = (uint32_t)k * BLOCK + tid;
+        const uint32_t c = RBs == 1 ? i : __umulhi(i, magic_s);
+        if (i < nwords) mapl[c * RB + (i - c * RBs)] = mv[k];
+    }
+    for (uint32_t i = MAPREG * BLOCK + tid; i < nwords; i += BLOCK) {  // schemas with many columns
+        const uint32_t c = RBs == 1 ? i : __umulhi(i, magic_s);
+        mapl[c * RB + (i - c * RBs)] = P.cellmap[(uint64_t)c * P.map_cap + slot + (i - c * RBs)];
+    }
+    // the map words of a later batch
     auto load_map = [&](uint32_t rb0, uint32_t RBn) {
         for (uint32_t c = wave; c <= ncols; c += BLOCK / 64) {
             const uint32_t *mp = P.cellmap + (uint64_t)c * P.map_cap + slot + rb0;
             for (uint32_t r = lane; r < RBn; r += 64) mapl[c * RB + r] = mp[r];
         }
     };
-    load_map(0, nrec < RB ? nrec : RB);
     __syncthreads();
     const SchemaHdr *H = (const SchemaHdr *)(smem + L.schema);
     const DevCol *cols = (const DevCol *)(H + 1);
@@ -1547,6 +1581,7 @@ hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_
 
 hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream) {
     if (P.ntiles == 0) return hipSuccess;
+    if (!P.cellmap || !P.map_stride) return hipSuccess;  // no map at all: the full write kernel does every tile
     hipError_t e = hipFuncSetAttribute((const void *)emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     uint32_t lds = P.L.total;
