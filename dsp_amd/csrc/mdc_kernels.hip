@@ -347,7 +347,7 @@ __device__ __forceinline__ uint32_t cell_filter_long(const uint8_t *src, uint32_
 template <bool EMIT>
 __device__ __forceinline__ uint32_t cell_scan16(uint64_t lo, uint64_t hi, uint32_t len, uint32_t lvl, bool nulcut,
                                                uint32_t typed, const double *p10, uint8_t *dst, uint64_t &value,
-                                               bool &valid) {
+                                               bool &valid, bool &later) {
     uint32_t out = 0;
     const bool isfloat = (typed == T_F64) | (typed == T_F32);
     const bool issigned = (typed == T_I32) | (typed == T_I64) | isfloat;
@@ -422,33 +422,18 @@ __device__ __forceinline__ uint32_t cell_scan16(uint64_t lo, uint64_t hi, uint32
         } else if (m < (1ull << 53)) {
             double x = (double)m / p10[k10];  // both exact (k10 <= 16): one correctly rounded division
             value = (uint64_t)__double_as_longlong(neg ? -x : x);
-        } else {
-            int e;
-            uint64_t mant;
-            u128 M;
-            M.hi = 0;
-            M.lo = m;
-            div_round(M, k10, 53, e, mant);
-            value = ((uint64_t)neg << 63) | ((uint64_t)(e + 1023) << 52) | (mant & ((1ull << 52) - 1));
+        } else {  // more than 53 bits of digits: the exact division is the second stage's business
+            valid = false;
+            later = true;
         }
         break;
-    default: {  // T_F32: one rounding, directly from the decimal
+    default:  // T_F32: one rounding, directly from the decimal (second stage), except for zero
         if (m == 0) {
             valid = true;
             value = neg ? 1ull << 31 : 0;
-            break;
+        } else {
+            later = true;
         }
-        int e;
-        uint64_t mant;
-        u128 M;
-        M.hi = 0;
-        M.lo = m;
-        div_round(M, k10, 24, e, mant);
-        if (e + 127 > 0 && e + 127 < 255) {
-            valid = true;
-            value = ((uint64_t)neg << 31) | ((uint64_t)(e + 127) << 23) | (mant & ((1ull << 23) - 1));
-        }
-    }
     }
     return out;
 }
@@ -502,7 +487,7 @@ __device__ __forceinline__ uint32_t parse4(uint32_t w) {
 // the converted value / validity.  D16 = digit bits of the window's bytes.
 __device__ __forceinline__ bool cell_fast(uint64_t lo, uint64_t hi, uint32_t len, uint32_t D16, uint32_t lvl,
                                           uint32_t typed, const double *p10, uint32_t &flen, uint64_t &value,
-                                          bool &valid, uint64_t &elo, uint64_t &ehi) {
+                                          bool &valid, uint64_t &elo, uint64_t &ehi, bool &later) {
     const uint32_t Lm = (1u << len) - 1;  // len <= 16
     const uint32_t D = D16 & Lm, N = ~D16 & Lm;
     const uint32_t N2 = N & (N - 1);
@@ -600,14 +585,9 @@ __device__ __forceinline__ bool cell_fast(uint64_t lo, uint64_t hi, uint32_t len
         } else if (m < (1ull << 53)) {
             const double x = (double)m / p10[k10];  // both exact (k10 <= 16): one correctly rounded division
             value = (uint64_t)__double_as_longlong(neg ? -x : x);
-        } else {
-            int e;
-            uint64_t mant;
-            u128 M;
-            M.hi = 0;
-            M.lo = m;
-            div_round(M, k10, 53, e, mant);
-            value = ((uint64_t)neg << 63) | ((uint64_t)(e + 1023) << 52) | (mant & ((1ull << 52) - 1));
+        } else {  // more than 53 bits of digits: left to the second stage
+            valid = false;
+            later = true;
         }
         break;
     }
@@ -712,7 +692,7 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
             const bool convert = typed != T_NONE && (found || E.nulcut);
             const uint32_t ty = (WRITE && convert) ? typed : (uint32_t)T_NONE;  // sizing needs lengths only
             uint64_t value = 0;
-            bool valid = false;
+            bool valid = false, later = false;
             if (len <= 16) {
                 const uint4 w4 = lds_u128(sdata + s);
                 const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
@@ -724,9 +704,10 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
                     ehi = hi;
                     fast = true;
                 } else if (!cutting && ty != T_F32 && ty != T_BOOL) {
-                    fast = cell_fast(lo, hi, len, digit_mask16(w4), lvl, ty, E.p10, flen, value, valid, elo, ehi);
+                    fast = cell_fast(lo, hi, len, digit_mask16(w4), lvl, ty, E.p10, flen, value, valid, elo, ehi, later);
                 }
-                if (!fast) flen = cell_scan16<false>(lo, hi, len, lvl, E.nulcut, ty, E.p10, nullptr, value, valid);
+                if (!fast) flen = cell_scan16<false>(lo, hi, len, lvl, E.nulcut, ty, E.p10, nullptr, value, valid, later);
+                if (later) deferred = true;
             } else {
                 flen = cell_filter_long<false>(sdata + s, len, lvl, E.nulcut, nullptr);
                 if (ty != T_NONE) deferred = true;  // value and valid bit come from the second stage
@@ -767,7 +748,7 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
                     } else if (cl_[ps] <= 16) {
                         const uint4 w4 = lds_u128(sdata + cs_[ps]);
                         cell_scan16<true>((uint64_t)w4.x | ((uint64_t)w4.y << 32), (uint64_t)w4.z | ((uint64_t)w4.w << 32),
-                                          cl_[ps], cv_[ps], E.nulcut, T_NONE, nullptr, dst, dv, b1);
+                                          cl_[ps], cv_[ps], E.nulcut, T_NONE, nullptr, dst, dv, b1, b1);
                     } else {
                         cell_filter_long<true>(sdata + cs_[ps], cl_[ps], cv_[ps], E.nulcut, dst);
                     }
