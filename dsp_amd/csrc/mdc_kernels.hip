@@ -1153,9 +1153,104 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         E.wstage_cap = L.stage_cap / (BLOCK / 64);
         const uint32_t slot = map_slot;
         const bool mapping = !WRITE && slot != NONE;
+        // the source of cell (c, r): start, length, filter level, found
+        auto fetch_cell = [&](uint32_t c, uint32_t r, uint32_t &s, uint32_t &len, uint32_t &lvl, bool &found) {
+            s = 0;
+            len = 0;
+            lvl = LVL_CHAR;
+            if (csv) {
+                const uint32_t d = desc[c * RB + r];
+                s = d & 0x7FFFu;
+                len = (d >> 15) & 0x7FFFu;
+                found = (fmask[r * W + (c >> 5)] >> (c & 31)) & 1u;
+                return;
+            }
+            // getxmlbuffer's independent first-open / first-close search, then splitbuffer's
+            // carry-forward: a missing tag keeps the nearest earlier column's value, filtered by
+            // every column in between
+            const uint32_t re = recend[r + 1];
+            uint32_t o = evt_get(evt, (2 * c) * RB + r), e = evt_get(evt, (2 * c + 1) * RB + r);
+            found = (o != NONE) & (e != NONE);
+            uint32_t cs = c;
+            lvl = cols[c].level;
+            bool have = found;
+            if (!found && carry) {
+                while (cs > 0) {
+                    --cs;
+                    o = evt_get(evt, (2 * cs) * RB + r);
+                    e = evt_get(evt, (2 * cs + 1) * RB + r);
+                    const uint32_t l2 = cols[cs].level;
+                    if (l2 > lvl) lvl = l2;
+                    if ((o != NONE) & (e != NONE)) {
+                        have = true;
+                        break;
+                    }
+                }
+            }
+            if (have) {
+                const uint32_t nml = cols[cs].namelen;
+                const int cl = cols[cs].collen;
+                s = o + nml + 2;
+                int l = (int)e - (int)s;
+                if (l < 0)
+                    l = (int)(re - s);  // close tag in front of the open tag: rest of record
+                else if (cl > 0 && cl < l)
+                    l = cl;
+                len = (uint32_t)l;
+            }
+        };
+        if (!WRITE) {
+            // Sizing needs the cells' lengths and the columns' totals only, no order among the
+            // cells: one lane per (column, record), all lanes busy.  A wave's lanes hold
+            // consecutive records of (usually) one or two columns; the last lane of each column's
+            // run adds the run's bytes to the column total.
+            const uint32_t nitems = ncols * RBn;
+            const uint32_t magic = 0xFFFFFFFFu / RBn + 1;  // i / RBn == umulhi(i, magic) for i < 2^15, RBn <= 256
+            for (uint32_t i0 = (uint32_t)wave * 64; i0 < nitems && !SKIP(2); i0 += BLOCK) {
+                const uint32_t i = i0 + lane;
+                const bool act = i < nitems;
+                const uint32_t c = !act ? ncols - 1 : RBn == 1 ? i : __umulhi(i, magic);
+                const uint32_t r = act ? i - c * RBn : 0;
+                uint32_t flen = 0;
+                if (act) {
+                    uint32_t s, len, lvl;
+                    bool found;
+                    fetch_cell(c, r, s, len, lvl, found);
+                    if (mapping) {
+                        if (len < MAP_MAXLEN)
+                            P.cellmap[(uint64_t)c * P.map_cap + slot + rb0 + r] = map_pack(s, len, lvl, found);
+                        else
+                            ms[MS_NOMAP] = 1;
+                    }
+                    if (len <= 16) {
+                        const uint4 w4 = lds_u128(sdata + s);
+                        const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
+                        const uint64_t hi = (uint64_t)w4.z | ((uint64_t)w4.w << 32);
+                        const bool cutting = lvl == LVL_CHAR && nulcut && has_nul;
+                        uint64_t value, elo, ehi;
+                        bool valid, later = false, fast = false;
+                        if (lvl == LVL_CHAR && !cutting) {
+                            flen = len;
+                            fast = true;
+                        } else if (!cutting) {
+                            fast = cell_fast(lo, hi, len, digit_mask16(w4), lvl, T_NONE, p10, flen, value, valid, elo, ehi, later);
+                        }
+                        if (!fast) flen = cell_scan16<false>(lo, hi, len, lvl, nulcut, T_NONE, p10, nullptr, value, valid, later);
+                    } else {
+                        flen = cell_filter_long<false>(sdata + s, len, lvl, nulcut, nullptr);
+                    }
+                }
+                const uint32_t incl = wave_incl_scan(flen);
+                // this column's run in the wave: lanes [first, last]
+                const uint32_t cstart = c * RBn, cend = cstart + RBn - 1;
+                const uint32_t first = cstart > i0 ? cstart - i0 : 0;
+                const uint32_t last = cend - i0 < 63 ? cend - i0 : 63;
+                const uint32_t before = __shfl(incl, first ? first - 1 : 0, 64);
+                if (act && (uint32_t)lane == last) atomicAdd(&tiletot[c], incl - (first ? before : 0));
+            }
+        } else
         for (uint32_t c = wave; c < ncols && !SKIP(2); c += BLOCK / 64) {
             const uint32_t typed = cols[c].typed;
-            const uint32_t clvl = cols[c].level;
             uint32_t cs_[RB_PASSES], cl_[RB_PASSES], cv_[RB_PASSES];
             bool fd_[RB_PASSES];
 #pragma unroll
@@ -1164,63 +1259,16 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 uint32_t s = 0, len = 0, lvl = LVL_CHAR;
                 bool found = false;
                 if (r < RBn) {
-                    const uint32_t idx = c * RB + r;
-                    if (csv) {
-                        const uint32_t d = desc[idx];
-                        s = d & 0x7FFFu;
-                        len = (d >> 15) & 0x7FFFu;
-                        found = (fmask[r * W + (c >> 5)] >> (c & 31)) & 1u;
-                    } else {
-                        // getxmlbuffer's independent first-open / first-close search, then
-                        // splitbuffer's carry-forward: a missing tag keeps the nearest earlier
-                        // column's value, filtered by every column in between
-                        const uint32_t re = recend[r + 1];
-                        uint32_t o = evt_get(evt, (2 * c) * RB + r), e = evt_get(evt, (2 * c + 1) * RB + r);
-                        found = (o != NONE) & (e != NONE);
-                        uint32_t cs = c;
-                        lvl = clvl;
-                        bool have = found;
-                        if (!found && carry) {
-                            while (cs > 0) {
-                                --cs;
-                                o = evt_get(evt, (2 * cs) * RB + r);
-                                e = evt_get(evt, (2 * cs + 1) * RB + r);
-                                const uint32_t l2 = cols[cs].level;
-                                if (l2 > lvl) lvl = l2;
-                                if ((o != NONE) & (e != NONE)) {
-                                    have = true;
-                                    break;
-                                }
-                            }
-                        }
-                        if (have) {
-                            const uint32_t nml = cols[cs].namelen;
-                            const int cl = cols[cs].collen;
-                            s = o + nml + 2;
-                            int l = (int)e - (int)s;
-                            if (l < 0)
-                                l = (int)(re - s);  // close tag in front of the open tag: rest of record
-                            else if (cl > 0 && cl < l)
-                                l = cl;
-                            len = (uint32_t)l;
-                        }
-                        if (found) atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
-                    }
-                    if (mapping) {
-                        if (len < MAP_MAXLEN)
-                            P.cellmap[(uint64_t)c * P.map_cap + slot + rb0 + r] = map_pack(s, len, lvl, found);
-                        else
-                            ms[MS_NOMAP] = 1;
-                    }
+                    fetch_cell(c, r, s, len, lvl, found);
+                    if (found && !csv) atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
                 }
                 cs_[ps] = s;
                 cl_[ps] = len;
                 cv_[ps] = lvl;
                 fd_[ps] = found;
             }
-            ColOut O = {};
-            if (WRITE) O = colout[c];
-            const uint64_t gb = WRITE ? O.base + tiletot[c] : 0;
+            const ColOut O = colout[c];
+            const uint64_t gb = O.base + tiletot[c];
             const uint32_t total = column_cells<WRITE>(E, O, c, typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
             if (lane == 0) tiletot[c] += total;  // this wave owns column c
         }
