@@ -46,6 +46,12 @@ EXPORTS = [
     "mdc_device_alloc", "mdc_device_free", "mdc_device_upload", "mdc_device_download",
     "mdc_device_synchronize",
 ]
+# every symbol include/mdc_format.h declares
+FORMAT_EXPORTS = [
+    "mdc_formatter_create", "mdc_formatter_destroy", "mdc_format_device", "mdc_format_host", "mdc_format_batch",
+    "mdc_formatter_last_timing", "mdc_text_files", "mdc_text_bytes", "mdc_text_file_range", "mdc_text_device",
+    "mdc_text_host", "mdc_text_write_files", "mdc_text_free",
+]
 
 
 class MdcError(RuntimeError):
@@ -75,6 +81,16 @@ class CTiming(ctypes.Structure):
         ("rows", ctypes.c_int64),
         ("tiles", ctypes.c_int),
         ("full_write", ctypes.c_int),
+    ]
+
+
+class CFormatTiming(ctypes.Structure):
+    _fields_ = [
+        ("format_ms", ctypes.c_float),
+        ("total_ms", ctypes.c_float),
+        ("bytes_in", ctypes.c_uint64),
+        ("bytes_out", ctypes.c_uint64),
+        ("exact_pass", ctypes.c_int),
     ]
 
 
@@ -135,6 +151,25 @@ def lib():
         L.mdc_device_upload.argtypes = [ci, vp, vp, sz]
         L.mdc_device_download.argtypes = [ci, vp, vp, sz]
         L.mdc_device_synchronize.argtypes = [ci]
+        u64 = ctypes.c_uint64
+        L.mdc_formatter_create.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ci), ci, ci, pp]
+        L.mdc_formatter_destroy.argtypes = [vp]
+        L.mdc_formatter_destroy.restype = None
+        L.mdc_format_device.argtypes = [vp, pp, pp, i64, i64, pp]
+        L.mdc_format_host.argtypes = [vp, pp, pp, i64, i64, pp]
+        L.mdc_format_batch.argtypes = [vp, vp, i64, pp]
+        L.mdc_formatter_last_timing.argtypes = [vp, ctypes.POINTER(CFormatTiming)]
+        L.mdc_text_files.argtypes = [vp]
+        L.mdc_text_files.restype = i64
+        L.mdc_text_bytes.argtypes = [vp]
+        L.mdc_text_bytes.restype = u64
+        L.mdc_text_file_range.argtypes = [vp, i64, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+        L.mdc_text_device.argtypes = [vp, pp, ctypes.POINTER(u64)]
+        L.mdc_text_host.argtypes = [vp, pp, ctypes.POINTER(u64)]
+        L.mdc_text_write_files.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                           ci, ctypes.POINTER(ci)]
+        L.mdc_text_free.argtypes = [vp]
+        L.mdc_text_free.restype = None
         _lib = L
     return _lib
 
@@ -345,3 +380,102 @@ class DeviceBuffer:
 
     def __del__(self):
         self.free()
+
+
+class Text:
+    """Formatted files back to back in HBM (mdc_text)."""
+
+    def __init__(self, handle: int):
+        self.h = ctypes.c_void_p(handle)
+
+    def free(self):
+        if self.h:
+            lib().mdc_text_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.free()
+
+    @property
+    def files(self) -> int:
+        return int(lib().mdc_text_files(self.h))
+
+    @property
+    def nbytes(self) -> int:
+        return int(lib().mdc_text_bytes(self.h))
+
+    def file_off(self) -> np.ndarray:
+        out = np.zeros(self.files + 1, dtype=np.uint64)
+        for k in range(self.files):
+            a, b = ctypes.c_uint64(), ctypes.c_uint64()
+            check(lib().mdc_text_file_range(self.h, k, ctypes.byref(a), ctypes.byref(b)))
+            out[k], out[k + 1] = a.value, b.value
+        return out
+
+    def device(self):
+        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+        check(lib().mdc_text_device(self.h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def host(self) -> np.ndarray:
+        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+        check(lib().mdc_text_host(self.h, ctypes.byref(p), ctypes.byref(n)))
+        return _np_from(p.value, n.value, np.uint8)
+
+    def write_files(self, outpath: str, bfilename: str, efilename: str, timestamp: Optional[str] = None,
+                    first_seq: int = 1) -> int:
+        n = ctypes.c_int(0)
+        check(lib().mdc_text_write_files(self.h, outpath.encode(), bfilename.encode(),
+                                         timestamp.encode() if timestamp is not None else None,
+                                         efilename.encode(), first_seq, ctypes.byref(n)))
+        return n.value
+
+
+class Formatter:
+    """A field list bound to one GPU (mdc_formatter): columns -> "<name>value</name>...<endl/>" text."""
+
+    def __init__(self, names: Sequence, fieldlen: Optional[Sequence[int]] = None, device: int = 0):
+        self.h = None
+        enc = [n.encode() if isinstance(n, str) else bytes(n) for n in names]
+        arr = (ctypes.c_char_p * max(1, len(enc)))(*enc)
+        fl = (ctypes.c_int * max(1, len(enc)))(*fieldlen) if fieldlen is not None else None
+        h = ctypes.c_void_p()
+        check(lib().mdc_formatter_create(arr, fl, len(enc), device, ctypes.byref(h)))
+        self.h = h
+        self.device = device
+        self.nfields = len(enc)
+
+    def close(self):
+        if self.h:
+            lib().mdc_formatter_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _ptrs(self, values):
+        return (ctypes.c_void_p * max(1, self.nfields))(*values)
+
+    def format_host(self, off: Sequence[np.ndarray], data: Sequence[np.ndarray], rows: int, maxcount: int = 0) -> Text:
+        offs = [np.ascontiguousarray(o, dtype=np.uint32) for o in off]
+        dats = [np.ascontiguousarray(d, dtype=np.uint8) if len(d) else np.zeros(1, np.uint8) for d in data]
+        h = ctypes.c_void_p()
+        check(lib().mdc_format_host(self.h, self._ptrs([o.ctypes.data for o in offs]),
+                                    self._ptrs([d.ctypes.data for d in dats]), rows, maxcount, ctypes.byref(h)))
+        return Text(h.value)
+
+    def format_device(self, d_off: Sequence[int], d_bytes: Sequence[int], rows: int, maxcount: int = 0) -> Text:
+        h = ctypes.c_void_p()
+        check(lib().mdc_format_device(self.h, self._ptrs(list(d_off)), self._ptrs(list(d_bytes)), rows, maxcount,
+                                      ctypes.byref(h)))
+        return Text(h.value)
+
+    def format_batch(self, batch: Batch, maxcount: int = 0) -> Text:
+        h = ctypes.c_void_p()
+        check(lib().mdc_format_batch(self.h, batch.h, maxcount, ctypes.byref(h)))
+        return Text(h.value)
+
+    def timing(self) -> CFormatTiming:
+        t = CFormatTiming()
+        check(lib().mdc_formatter_last_timing(self.h, ctypes.byref(t)))
+        return t

@@ -7,6 +7,7 @@
 // with MDC_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +17,12 @@
 #include <string>
 #include <vector>
 
+#include <ctime>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "mdc_device.h"
+#include "mdc_format.h"
 #include "mdc_parse.h"
 
 namespace mdc {
@@ -30,6 +36,12 @@ hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_
                              uint32_t ncols, hipStream_t stream);
 hipError_t launch_fixed_stride(const uint32_t *off, const uint8_t *bytes, uint8_t *slab, uint64_t rows,
                                uint32_t stride, hipStream_t stream);
+hipError_t launch_format_prep(const uint32_t *const *off, const uint64_t *nbytes, uint32_t ncols, uint64_t rows,
+                              uint64_t *info, hipStream_t stream);
+hipError_t launch_format(bool exact, const FormatParams &P, hipStream_t stream);
+uint32_t format_scan_parts(uint64_t rows);
+hipError_t launch_format_measure(const FormatParams &P, uint32_t *elen, uint64_t *reclen, uint64_t *part,
+                                 uint64_t *recpos, hipStream_t stream);
 }  // namespace mdc
 
 using namespace mdc;
@@ -1036,6 +1048,433 @@ extern "C" int mdc_batch_column_fixed(mdc_batch *b, int col, const char **base, 
     if (base) *base = b->h_fixed[col].data();
     if (stride) *stride = b->fixed_stride[col];
     return MDC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// writer side: columns -> text (include/mdc_format.h)
+
+struct mdc_formatter {
+    Device *dev = nullptr;
+    int ncols = 0;
+    std::vector<uint8_t> blob;
+    uint32_t const_off = 0;
+    uint32_t fixed = 0;          // bytes per record that are not values
+    uint32_t lds_budget = 20 * 1024;
+    void *d_blob = nullptr;
+    void *d_tab = nullptr;       // ncols off pointers, ncols byte pointers, ncols arena sizes
+    void *h_tab = nullptr;       // pinned image of d_tab
+    uint64_t *d_info = nullptr;  // prep sums (3 words), status word
+    uint64_t *h_info = nullptr;  // pinned
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    mdc_format_timing timing{};
+};
+
+struct mdc_text {
+    Device *dev = nullptr;
+    uint8_t *d_data = nullptr;
+    uint64_t nbytes = 0;
+    int64_t maxcount = 0;
+    std::vector<uint64_t> file_off; // files + 1 entries
+    std::vector<uint8_t> h_data;
+    bool have_host = false;
+};
+
+extern "C" int mdc_formatter_create(const char *const *fieldname, const int *fieldlen, int nfields, int device,
+                                    mdc_formatter **out) {
+    if (!out) return fail(MDC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!fieldname || nfields < 1 || nfields > 128) return fail(MDC_ERR_ARG, "1..128 fields required");
+    size_t text = 0;
+    for (int c = 0; c < nfields; ++c) {
+        if (!fieldname[c]) return fail(MDC_ERR_ARG, "field %d: name is NULL", c);
+        size_t nl = strlen(fieldname[c]);
+        if (nl < 1 || nl > 255) return fail(MDC_ERR_ARG, "field %d: name of %zu bytes (1..255 allowed)", c, nl);
+        if (fieldlen && fieldlen[c] < 0) return fail(MDC_ERR_ARG, "field %d: negative fieldlen", c);
+        text += 2 * nl + 5;
+    }
+    if (text > 12 * 1024) return fail(MDC_ERR_ARG, "%zu bytes of tag text (12 KiB allowed)", text);
+    Device *d;
+    int rc = get_device(device, &d);
+    if (rc) return rc;
+
+    mdc_formatter *f = new mdc_formatter();
+    f->dev = d;
+    f->ncols = nfields;
+    f->fixed = (uint32_t)text + 8;
+    f->blob.assign(sizeof(FormatField) * nfields, 0);
+    for (int c = 0; c < nfields; ++c) {
+        FormatField ff{};
+        ff.text_off = (uint32_t)f->blob.size();
+        ff.name_len = (uint32_t)strlen(fieldname[c]);
+        ff.fieldlen = fieldlen ? (uint32_t)fieldlen[c] : 0;
+        memcpy(f->blob.data() + sizeof(FormatField) * c, &ff, sizeof ff);
+        std::string t = std::string("<") + fieldname[c] + "></" + fieldname[c] + ">";
+        f->blob.insert(f->blob.end(), t.begin(), t.end());
+    }
+    f->const_off = (uint32_t)f->blob.size();
+    const char *consts = "<endl/>\n</data>\n<data>\n";
+    f->blob.insert(f->blob.end(), consts, consts + 23);
+    f->blob.resize((f->blob.size() + 15) & ~size_t(15), 0);
+
+    auto bail = [&](int code) {
+        mdc_formatter_destroy(f);
+        return code;
+    };
+    if (hipSetDevice(d->id) != hipSuccess) return bail(fail(MDC_ERR_HIP, "hipSetDevice failed"));
+    if ((rc = dev_alloc(d, f->blob.size(), &f->d_blob))) return bail(rc);
+    if ((rc = dev_alloc(d, (size_t)nfields * 24, &f->d_tab))) return bail(rc);
+    if ((rc = dev_alloc(d, 64, (void **)&f->d_info))) return bail(rc);
+    hipError_t e = hipHostMalloc(&f->h_tab, (size_t)nfields * 24);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&f->h_info, 64);
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&f->ev[i]);
+    if (e == hipSuccess) e = hipMemcpy(f->d_blob, f->blob.data(), f->blob.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(fail(MDC_ERR_HIP, "formatter set-up: %s", hipGetErrorString(e)));
+    *out = f;
+    return MDC_OK;
+}
+
+extern "C" void mdc_formatter_destroy(mdc_formatter *f) {
+    if (!f) return;
+    if (f->dev) {
+        (void)hipSetDevice(f->dev->id);
+        dev_free(f->dev, f->d_blob);
+        dev_free(f->dev, f->d_tab);
+        dev_free(f->dev, f->d_info);
+    }
+    if (f->h_tab) (void)hipHostFree(f->h_tab);
+    if (f->h_info) (void)hipHostFree(f->h_info);
+    for (auto &e : f->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete f;
+}
+
+// tuning hook for the measurement tools: LDS bytes a block of the formatting kernel may take
+extern "C" int mdc_internal_format_budget(mdc_formatter *f, int bytes) {
+    if (!f || bytes < 8 * 1024 || bytes > 60 * 1024) return fail(MDC_ERR_ARG, "budget out of range");
+    f->lds_budget = (uint32_t)bytes;
+    return MDC_OK;
+}
+
+// Rows per block and the LDS regions: the largest power of two whose rows' text is expected to
+// fit one staging window within the budget (longer rows go through several windows).
+static void format_layout(const mdc_formatter *f, uint64_t rows, uint64_t total, FormatParams &P) {
+    const uint32_t nc = (uint32_t)f->ncols;
+    const uint32_t head = (uint32_t)f->blob.size() + 16 * nc;
+    const uint32_t budget = std::max(f->lds_budget, head + 12 * 1024);
+    const uint64_t avg = rows ? (total + rows - 1) / rows : 1;
+    uint32_t R = FMT_BLOCK, shift = 8;
+    auto tables = [&](uint32_t r) { return round16((nc + 1) * r * 4) + round16(r * 9) + 32; };
+    while (R > 1) {
+        uint64_t want = (avg * R * 9 / 8 + 48 + 15) & ~uint64_t(15);
+        if (head + tables(R) + want <= budget) break;
+        R >>= 1;
+        --shift;
+    }
+    P.R = R;
+    P.Rshift = shift;
+    P.lds_ptrs = (uint32_t)f->blob.size();
+    P.lds_cpos = head;
+    P.lds_rstart = round16(P.lds_cpos + (nc + 1) * R * 4);
+    P.lds_rflag = P.lds_rstart + R * 8;
+    P.lds_misc = round16(P.lds_rflag + R);
+    P.lds_stage = P.lds_misc + 32;
+    uint32_t room = budget > P.lds_stage ? (budget - P.lds_stage) & ~15u : 0;
+    P.stage_cap = std::max(room, 4096u);
+    P.lds_total = P.lds_stage + P.stage_cap;
+}
+
+static int format_columns(mdc_formatter *f, const uint32_t *const *d_off, const uint8_t *const *d_bytes,
+                          const uint64_t *nbytes, int64_t rows, int64_t maxcount, mdc_text **out) {
+    Device *d = f->dev;
+    const uint32_t nc = (uint32_t)f->ncols;
+    HIP_TRY(hipSetDevice(d->id));
+    mdc_text *t = new mdc_text();
+    t->dev = d;
+    t->maxcount = maxcount;
+    t->file_off.assign(1, 0);
+    f->timing = mdc_format_timing{};
+    if (rows == 0) {
+        *out = t;
+        return MDC_OK;
+    }
+    auto bail = [&](int code) {
+        mdc_text_free(t);
+        return code;
+    };
+#define FMT_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return bail(fail(MDC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_))); \
+    } while (0)
+
+    // the columns' pointers, then the sums of their first and last offsets
+    const void **tab = (const void **)f->h_tab;
+    for (uint32_t c = 0; c < nc; ++c) {
+        tab[c] = d_off[c];
+        tab[nc + c] = d_bytes[c];
+        ((uint64_t *)f->h_tab)[2 * nc + c] = nbytes ? nbytes[c] : 0;
+    }
+    hipStream_t st = d->stream;
+    FMT_TRY(hipEventRecord(f->ev[0], st));
+    FMT_TRY(hipMemcpyAsync(f->d_tab, f->h_tab, (size_t)nc * 24, hipMemcpyHostToDevice, st));
+    FMT_TRY(hipMemsetAsync(f->d_info, 0, 64, st));
+    const uint32_t *const *t_off = (const uint32_t *const *)f->d_tab;
+    const uint8_t *const *t_bytes = (const uint8_t *const *)((const void **)f->d_tab + nc);
+    const uint64_t *t_nbytes = nbytes ? (const uint64_t *)f->d_tab + 2 * nc : nullptr;
+    FMT_TRY(launch_format_prep(t_off, t_nbytes, nc, (uint64_t)rows, f->d_info, st));
+    FMT_TRY(hipMemcpyAsync(f->h_info, f->d_info, 32, hipMemcpyDeviceToHost, st));
+    FMT_TRY(hipStreamSynchronize(st));
+    if (f->h_info[2])
+        return bail(fail(MDC_ERR_ARG, "a column's offsets descend or pass the end of its arena"));
+    const uint64_t cells = f->h_info[0] - f->h_info[1];
+    const uint64_t nfiles = maxcount > 0 ? ((uint64_t)rows + maxcount - 1) / (uint64_t)maxcount : 1;
+    uint64_t total = (uint64_t)rows * f->fixed + cells + 15 * nfiles;
+
+    FormatParams P{};
+    P.off = t_off;
+    P.bytes = t_bytes;
+    P.blob = (const uint8_t *)f->d_blob;
+    P.blob_bytes = (uint32_t)f->blob.size();
+    P.const_off = f->const_off;
+    P.ncols = nc;
+    P.fixed = f->fixed;
+    P.rows = (uint64_t)rows;
+    P.maxcount = (uint64_t)maxcount;
+    P.sumbase = f->h_info[1];
+    P.total = total;
+    P.status = (uint32_t *)(f->d_info + 3);
+    format_layout(f, P.rows, total, P);
+    if (((P.rows + P.R - 1) >> P.Rshift) > 0x7fffffffull)
+        return bail(fail(MDC_ERR_TOO_LARGE, "%lld rows in one call", (long long)rows));
+
+    int rc;
+    void *d_fo = nullptr, *d_elen = nullptr, *d_len = nullptr, *d_pos = nullptr, *d_part = nullptr;
+    if ((rc = dev_alloc(d, total + 64, (void **)&t->d_data))) return bail(rc);
+    if ((rc = dev_alloc(d, (nfiles + 1) * 8, &d_fo))) return bail(rc);
+    auto release = [&]() {
+        dev_free(d, d_fo);
+        dev_free(d, d_elen);
+        dev_free(d, d_len);
+        dev_free(d, d_pos);
+        dev_free(d, d_part);
+    };
+    auto bail2 = [&](int code) {
+        release();
+        return bail(code);
+    };
+#define FMT_TRY2(expr)                                                                            \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return bail2(fail(MDC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_))); \
+    } while (0)
+    P.out = t->d_data;
+    P.file_off = (uint64_t *)d_fo;
+
+    FMT_TRY2(hipEventRecord(f->ev[1], st));
+    FMT_TRY2(launch_format(false, P, st));
+    FMT_TRY2(hipEventRecord(f->ev[2], st));
+    FMT_TRY2(hipMemcpyAsync(f->h_info, f->d_info, 32, hipMemcpyDeviceToHost, st));
+    FMT_TRY2(hipStreamSynchronize(st));
+    uint32_t status = (uint32_t)f->h_info[3];
+    int exact = 0;
+    if (!(status & FS_BAD_OFFSETS) && (status & FS_NEED_EXACT)) {
+        // some value is cut: measure every value, scan the record lengths, format again
+        exact = 1;
+        const uint32_t np = format_scan_parts(P.rows);
+        if ((rc = dev_alloc(d, (size_t)nc * P.rows * 4, &d_elen))) return bail2(rc);
+        if ((rc = dev_alloc(d, P.rows * 8, &d_len))) return bail2(rc);
+        if ((rc = dev_alloc(d, (P.rows + 1) * 8, &d_pos))) return bail2(rc);
+        if ((rc = dev_alloc(d, (size_t)np * 8, &d_part))) return bail2(rc);
+        FMT_TRY2(hipMemsetAsync(f->d_info, 0, 64, st));
+        FMT_TRY2(launch_format_measure(P, (uint32_t *)d_elen, (uint64_t *)d_len, (uint64_t *)d_part,
+                                       (uint64_t *)d_pos, st));
+        FMT_TRY2(hipMemcpyAsync(f->h_info, (uint64_t *)d_pos + P.rows, 8, hipMemcpyDeviceToHost, st));
+        FMT_TRY2(hipStreamSynchronize(st));
+        total = f->h_info[0] + 15 * nfiles;
+        if (total > P.total) return bail2(fail(MDC_ERR_INTERNAL, "measured text longer than its bound"));
+        P.total = total;
+        P.elen = (const uint32_t *)d_elen;
+        P.recpos = (const uint64_t *)d_pos;
+        FMT_TRY2(hipEventRecord(f->ev[1], st));
+        FMT_TRY2(launch_format(true, P, st));
+        FMT_TRY2(hipEventRecord(f->ev[2], st));
+        FMT_TRY2(hipMemcpyAsync(f->h_info, f->d_info, 32, hipMemcpyDeviceToHost, st));
+        FMT_TRY2(hipStreamSynchronize(st));
+        status = (uint32_t)f->h_info[3];
+    }
+    if (status & FS_BAD_OFFSETS) return bail2(fail(MDC_ERR_ARG, "a column's offsets descend"));
+    t->nbytes = total;
+    t->file_off.assign(nfiles + 1, 0);
+    FMT_TRY2(hipMemcpy(t->file_off.data(), d_fo, nfiles * 8, hipMemcpyDeviceToHost));
+    t->file_off[nfiles] = total;
+    release();
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, f->ev[1], f->ev[2]);
+    f->timing.format_ms = ms;
+    (void)hipEventElapsedTime(&ms, f->ev[0], f->ev[2]);
+    f->timing.total_ms = ms;
+    f->timing.bytes_in = cells + (uint64_t)nc * ((uint64_t)rows + 1) * 4;
+    f->timing.bytes_out = total;
+    f->timing.exact_pass = exact;
+    *out = t;
+    return MDC_OK;
+#undef FMT_TRY
+#undef FMT_TRY2
+}
+
+extern "C" int mdc_format_device(mdc_formatter *f, const uint32_t *const *d_off, const uint8_t *const *d_bytes,
+                                 int64_t rows, int64_t maxcount, mdc_text **out) {
+    if (!f || !out) return fail(MDC_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    if (rows < 0 || maxcount < 0) return fail(MDC_ERR_ARG, "negative rows or maxcount");
+    if (rows && (!d_off || !d_bytes)) return fail(MDC_ERR_ARG, "column arrays are NULL");
+    for (int c = 0; rows && c < f->ncols; ++c)
+        if (!d_off[c] || !d_bytes[c]) return fail(MDC_ERR_ARG, "column %d: NULL pointer", c);
+    return format_columns(f, d_off, d_bytes, nullptr, rows, maxcount, out);
+}
+
+extern "C" int mdc_format_batch(mdc_formatter *f, const mdc_batch *b, int64_t maxcount, mdc_text **out) {
+    if (!f || !b || !out) return fail(MDC_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    if (maxcount < 0) return fail(MDC_ERR_ARG, "negative maxcount");
+    if (b->ncols != f->ncols)
+        return fail(MDC_ERR_ARG, "batch has %d columns, formatter %d fields", b->ncols, f->ncols);
+    if (b->dev != f->dev) return fail(MDC_ERR_ARG, "batch and formatter live on different devices");
+    std::vector<const uint32_t *> off(b->d_off.begin(), b->d_off.end());
+    std::vector<const uint8_t *> bytes(b->d_bytes.begin(), b->d_bytes.end());
+    return format_columns(f, off.data(), bytes.data(), b->nbytes.data(), b->rows, maxcount, out);
+}
+
+extern "C" int mdc_format_host(mdc_formatter *f, const uint32_t *const *off, const uint8_t *const *bytes,
+                               int64_t rows, int64_t maxcount, mdc_text **out) {
+    if (!f || !out) return fail(MDC_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    if (rows < 0 || maxcount < 0) return fail(MDC_ERR_ARG, "negative rows or maxcount");
+    if (rows && (!off || !bytes)) return fail(MDC_ERR_ARG, "column arrays are NULL");
+    Device *d = f->dev;
+    HIP_TRY(hipSetDevice(d->id));
+    const int nc = f->ncols;
+    std::vector<void *> d_off(nc, nullptr), d_bytes(nc, nullptr);
+    std::vector<uint64_t> nbytes(nc, 0);
+    auto release = [&]() {
+        for (int c = 0; c < nc; ++c) {
+            dev_free(d, d_off[c]);
+            dev_free(d, d_bytes[c]);
+        }
+    };
+    int rc = MDC_OK;
+    for (int c = 0; rows && c < nc && rc == MDC_OK; ++c) {
+        if (!off[c] || (!bytes[c] && off[c][rows])) {
+            rc = fail(MDC_ERR_ARG, "column %d: NULL pointer", c);
+            break;
+        }
+        nbytes[c] = off[c][rows];
+        if ((rc = dev_alloc(d, ((size_t)rows + 1) * 4, &d_off[c]))) break;
+        if ((rc = dev_alloc(d, nbytes[c] + 64, &d_bytes[c]))) break;
+        hipError_t e = hipMemcpyAsync(d_off[c], off[c], ((size_t)rows + 1) * 4, hipMemcpyHostToDevice, d->stream);
+        if (e == hipSuccess && nbytes[c])
+            e = hipMemcpyAsync(d_bytes[c], bytes[c], nbytes[c], hipMemcpyHostToDevice, d->stream);
+        if (e != hipSuccess) rc = fail(MDC_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+    }
+    if (rc == MDC_OK && hipStreamSynchronize(d->stream) != hipSuccess) rc = fail(MDC_ERR_HIP, "H2D copy failed");
+    if (rc == MDC_OK)
+        rc = format_columns(f, (const uint32_t *const *)d_off.data(), (const uint8_t *const *)d_bytes.data(),
+                            nbytes.data(), rows, maxcount, out);
+    release();
+    return rc;
+}
+
+extern "C" int mdc_formatter_last_timing(const mdc_formatter *f, mdc_format_timing *t) {
+    if (!f || !t) return fail(MDC_ERR_ARG, "NULL argument");
+    *t = f->timing;
+    return MDC_OK;
+}
+
+extern "C" int64_t mdc_text_files(const mdc_text *t) { return t ? (int64_t)t->file_off.size() - 1 : -1; }
+extern "C" uint64_t mdc_text_bytes(const mdc_text *t) { return t ? t->nbytes : 0; }
+
+extern "C" int mdc_text_file_range(const mdc_text *t, int64_t k, uint64_t *begin, uint64_t *end) {
+    if (!t || !begin || !end) return fail(MDC_ERR_ARG, "NULL argument");
+    if (k < 0 || k + 1 >= (int64_t)t->file_off.size()) return fail(MDC_ERR_ARG, "file %lld out of range", (long long)k);
+    *begin = t->file_off[k];
+    *end = t->file_off[k + 1];
+    return MDC_OK;
+}
+
+extern "C" int mdc_text_device(const mdc_text *t, const uint8_t **d_data, uint64_t *nbytes) {
+    if (!t || !d_data || !nbytes) return fail(MDC_ERR_ARG, "NULL argument");
+    *d_data = t->d_data;
+    *nbytes = t->nbytes;
+    return MDC_OK;
+}
+
+extern "C" int mdc_text_host(mdc_text *t, const uint8_t **data, uint64_t *nbytes) {
+    if (!t || !data || !nbytes) return fail(MDC_ERR_ARG, "NULL argument");
+    if (!t->have_host) {
+        t->h_data.resize(t->nbytes);
+        if (t->nbytes) {
+            int rc = d2h(t->dev, t->h_data.data(), t->d_data, t->nbytes);
+            if (rc) return rc;
+        }
+        t->have_host = true;
+    }
+    *data = t->h_data.data();
+    *nbytes = t->nbytes;
+    return MDC_OK;
+}
+
+// create the directories above a file name, as cofile::open does through newdir(name,true)
+// (public/_public.cpp:952-977)
+static bool make_parent_dirs(const std::string &name) {
+    for (size_t pos = name.find('/', 1); pos != std::string::npos; pos = name.find('/', pos + 1)) {
+        std::string dir = name.substr(0, pos);
+        if (access(dir.c_str(), F_OK) != 0 && mkdir(dir.c_str(), 0755) != 0) return false;
+    }
+    return true;
+}
+
+extern "C" int mdc_text_write_files(mdc_text *t, const char *outpath, const char *bfilename, const char *timestamp,
+                                    const char *efilename, int first_seq, int *nwritten) {
+    if (!t || !outpath || !bfilename || !efilename) return fail(MDC_ERR_ARG, "NULL argument");
+    if (nwritten) *nwritten = 0;
+    const int64_t nfiles = (int64_t)t->file_off.size() - 1;
+    if (nfiles == 0) {
+        if (t->maxcount == 0) return fail(MDC_ERR_IO, "no rows and maxcount 0: no file is open to close");
+        return MDC_OK;
+    }
+    char stamp[32];
+    if (!timestamp) {
+        time_t now = time(nullptr);
+        struct tm tmv;
+        localtime_r(&now, &tmv);
+        strftime(stamp, sizeof stamp, "%Y%m%d%H%M%S", &tmv);
+        timestamp = stamp;
+    }
+    const uint8_t *data;
+    uint64_t n;
+    int rc = mdc_text_host(t, &data, &n);
+    if (rc) return rc;
+    for (int64_t k = 0; k < nfiles; ++k) {
+        std::string name = std::string(outpath) + "/" + bfilename + "_" + timestamp + "_" + efilename + "_" +
+                           std::to_string(first_seq + (int)k) + ".xml";
+        std::string tmp = name + ".tmp";
+        make_parent_dirs(name);
+        FILE *fp = fopen(tmp.c_str(), "wb");
+        if (!fp) return fail(MDC_ERR_IO, "cannot open %s", tmp.c_str());
+        const size_t len = (size_t)(t->file_off[k + 1] - t->file_off[k]);
+        bool ok = fwrite(data + t->file_off[k], 1, len, fp) == len;
+        ok = (fclose(fp) == 0) && ok;
+        if (!ok) return fail(MDC_ERR_IO, "write to %s failed", tmp.c_str());
+        if (rename(tmp.c_str(), name.c_str()) != 0) return fail(MDC_ERR_IO, "rename of %s failed", tmp.c_str());
+        if (nwritten) *nwritten = (int)(k + 1);
+    }
+    return MDC_OK;
+}
+
+extern "C" void mdc_text_free(mdc_text *t) {
+    if (!t) return;
+    if (t->dev) dev_free(t->dev, t->d_data);
+    delete t;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -135,4 +135,45 @@ struct TileParams {
     uint32_t debug;  // diagnostic builds only: phases to skip (ablation timing)
 };
 
+// ------------------------------------------------------------------------------------------
+// writer side (mdc_format.hip): columns -> "<name>value</name>...<endl/>\n" text
+
+// status bits of the formatting kernels
+constexpr uint32_t FS_NEED_EXACT = 1;  // a value holds a NUL byte or exceeds its fieldlen
+constexpr uint32_t FS_BAD_OFFSETS = 2; // a column's offsets descend or pass the end of its arena
+
+constexpr int FMT_BLOCK = 256;
+
+// Field table at the head of the formatter's blob, one entry per field; the tag text follows:
+// "<name>" at text_off, "</name>" right after it.  The blob ends with the 23 bytes
+// "<endl/>\n</data>\n<data>\n" at FormatParams::const_off.
+struct FormatField {
+    uint32_t text_off;
+    uint32_t name_len;
+    uint32_t fieldlen; // 0 = no cut
+    uint32_t pad;
+};
+
+struct FormatParams {
+    const uint32_t *const *off;  // device array [ncols] -> rows+1 offsets
+    const uint8_t *const *bytes; // device array [ncols] -> arenas
+    const uint8_t *blob;
+    uint32_t blob_bytes;         // multiple of 16
+    uint32_t const_off;
+    uint32_t ncols;
+    uint32_t R, Rshift;          // records per block, a power of two <= FMT_BLOCK
+    uint32_t fixed;              // bytes of a record that are not values: tags and "<endl/>\n"
+    uint64_t rows, maxcount;
+    uint64_t sumbase;            // sum over columns of off[c][0]
+    uint64_t total;              // length of the whole text
+    uint8_t *out;
+    uint64_t *file_off;          // start of every file
+    uint32_t *status;
+    // exact mode: lengths measured beforehand
+    const uint32_t *elen;        // [ncols][rows] value lengths after the cuts
+    const uint64_t *recpos;      // [rows+1] record starts, file framing not counted
+    // LDS regions (byte offsets)
+    uint32_t lds_ptrs, lds_cpos, lds_rstart, lds_rflag, lds_misc, lds_stage, stage_cap, lds_total;
+};
+
 }  // namespace mdc

@@ -1,0 +1,364 @@
+// mdc_format.hip -- writer-side kernels of libmdc_parse.so (gfx950).
+//
+// Columns (u32 offsets + byte arena each) -> the text of the reference's extractor,
+// tools/dminingoracle.cpp:196-256: per row "<name>value</name>" for every field, "<endl/>\n",
+// files framed by "<data>\n" and "</data>\n" and closed after every maxcount rows.
+//
+// Where no value needs cutting, the start of every record follows in closed form from the
+// column offsets (row index x tag bytes + sum of the columns' offsets + file framing), so one
+// kernel does all the work: a block takes R consecutive rows, lays their text out in LDS and
+// copies it to HBM in 16-byte stores.  Values with a NUL byte, or longer than their fieldlen,
+// are found on the way and reported; the host then measures every value (format_measure_kernel),
+// scans the record lengths and runs the same kernel in its exact mode.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "mdc_device.h"
+
+namespace mdc {
+
+typedef __attribute__((address_space(1))) const uint8_t fg_u8;
+typedef __attribute__((address_space(1))) const uint32_t fg_u32;
+typedef uint32_t fu32x4 __attribute__((ext_vector_type(4)));
+
+// Where row r falls among the files of maxcount rows each (maxcount 0: one file).
+struct FilePos {
+    uint64_t file;    // index of the row's file
+    uint64_t framing; // bytes of "<data>\n" (7) and "</data>\n" (8) written before the row's own first byte
+    bool opens, closes;
+};
+
+__device__ __forceinline__ FilePos file_pos(uint64_t r, uint64_t m, uint64_t rows) {
+    FilePos f;
+    uint64_t q = 0, rem = r;
+    if (m) {
+        if ((r | m) >> 32) {
+            q = r / m;
+            rem = r % m;
+        } else {
+            q = (uint32_t)r / (uint32_t)m;
+            rem = (uint32_t)r % (uint32_t)m;
+        }
+    }
+    f.file = q;
+    f.opens = rem == 0;
+    f.closes = (m && rem + 1 == m) || r + 1 == rows;
+    f.framing = m ? 7 * (q + (rem ? 1 : 0)) + 8 * q : (r ? 7 : 0);
+    return f;
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(FMT_BLOCK) void format_kernel(const FormatParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t R = P.R, ncols = P.ncols;
+    const uint64_t r0 = (uint64_t)blockIdx.x << P.Rshift;
+    const uint32_t nrec = (uint32_t)(P.rows - r0 < R ? P.rows - r0 : R);
+
+    const FormatField *fld = (const FormatField *)lds;
+    const uint32_t *const *offp = (const uint32_t *const *)(lds + P.lds_ptrs);
+    const uint8_t *const *bytp = (const uint8_t *const *)(lds + P.lds_ptrs + 8 * ncols);
+    uint32_t *cpos = (uint32_t *)(lds + P.lds_cpos);
+    uint64_t *rstart = (uint64_t *)(lds + P.lds_rstart);
+    uint8_t *rflag = lds + P.lds_rflag;
+    uint64_t *misc = (uint64_t *)(lds + P.lds_misc); // [0] block start, [1] block end, [2] bad
+    uint8_t *stage = lds + P.lds_stage;
+    const uint32_t STAGE = P.stage_cap;
+
+    for (uint32_t i = lane * 16; i < P.blob_bytes; i += FMT_BLOCK * 16)
+        *(fu32x4 *)(lds + i) = *(const fu32x4 *)(P.blob + i);
+    for (uint32_t c = lane; c < ncols; c += FMT_BLOCK) {
+        ((const uint32_t **)(lds + P.lds_ptrs))[c] = P.off[c];
+        ((const uint8_t **)(lds + P.lds_ptrs + 8 * ncols))[c] = P.bytes[c];
+    }
+    if (lane == 0) misc[2] = 0;
+    __syncthreads();
+
+    // one lane per row: where its fields start, where the row starts
+    if (lane < nrec) {
+        const uint64_t r = r0 + lane;
+        uint64_t sum = 0;
+        uint32_t run = 0, bad = 0, cut = 0;
+#pragma unroll 4
+        for (uint32_t c = 0; c < ncols; ++c) {
+            fg_u32 *o = (fg_u32 *)offp[c];
+            uint32_t a = o[r], b = o[r + 1];
+            uint32_t len = b - a;
+            if (b < a) {
+                bad = 1;
+                len = 0;
+            }
+            const uint32_t fl = fld[c].fieldlen;
+            if (EXACT)
+                len = ((fg_u32 *)P.elen)[(uint64_t)c * P.rows + r];
+            else if (fl && len > fl)
+                cut = 1;
+            cpos[c * R + lane] = run;
+            run += 2 * fld[c].name_len + 5 + len;
+            sum += a;
+        }
+        cpos[ncols * R + lane] = run;
+        const uint64_t body = EXACT ? P.recpos[r] : r * P.fixed + sum - P.sumbase;
+        const FilePos fp = file_pos(r, P.maxcount, P.rows);
+        const uint64_t start = body + fp.framing;
+        const bool op = fp.opens, cl = fp.closes;
+        rstart[lane] = start + (op ? 7 : 0);
+        rflag[lane] = (op ? 1 : 0) | (cl ? 2 : 0);
+        if (lane == 0) misc[0] = start;
+        if (lane == nrec - 1) misc[1] = start + (op ? 7 : 0) + run + 8 + (cl ? 8 : 0);
+        if (bad) misc[2] = 1;
+        if (cut) atomicOr(P.status, FS_NEED_EXACT);
+        if (op && !bad) P.file_off[fp.file] = start;
+    }
+    __syncthreads();
+    if (misc[2]) {
+        if (lane == 0) atomicOr(P.status, FS_BAD_OFFSETS);
+        return;
+    }
+    const uint64_t blk_lo = misc[0];
+    const uint64_t blk_hi = misc[1] < P.total ? misc[1] : P.total;
+    if (blk_lo >= blk_hi) return;
+
+    const uint8_t *consts = lds + P.const_off; // "<endl/>\n</data>\n<data>\n"
+    const uint32_t units = (ncols + 1) << P.Rshift;
+    uint32_t sawcut = 0;
+
+    for (uint64_t wlo = blk_lo & ~15ull; wlo < blk_hi; wlo += STAGE) {
+        const uint64_t whi = wlo + STAGE;
+        // bytes [k0, k1) of a piece of n bytes at text position p that fall into this window
+        auto clip = [&](uint64_t p, uint32_t n, uint32_t &k0, uint32_t &k1) {
+            k0 = p >= wlo ? 0 : (wlo - p < n ? (uint32_t)(wlo - p) : n);
+            k1 = p + n <= whi ? n : (p >= whi ? 0 : (uint32_t)(whi - p));
+        };
+        auto put_lds = [&](uint64_t p, const uint8_t *src, uint32_t n) {
+            uint32_t k0, k1;
+            clip(p, n, k0, k1);
+            const uint32_t s = (uint32_t)(p - wlo); // exact modulo 2^32 for the bytes in range
+            for (uint32_t k = k0; k < k1; ++k) stage[s + k] = src[k];
+        };
+
+        for (uint32_t u = lane; u < units; u += FMT_BLOCK) {
+            const uint32_t i = u & (R - 1), c = u >> P.Rshift;
+            if (i >= nrec) continue;
+            const uint64_t dst = rstart[i] + cpos[c * R + i];
+            if (c == ncols) {
+                const uint32_t fl = rflag[i];
+                put_lds(dst, consts, (fl & 2) ? 16 : 8);
+                if (fl & 1) put_lds(rstart[i] - 7, consts + 16, 7);
+                continue;
+            }
+            const uint32_t nl = fld[c].name_len;
+            const uint32_t len = cpos[(c + 1) * R + i] - cpos[c * R + i] - (2 * nl + 5);
+            if (dst + 2 * nl + 5 + len <= wlo || dst >= whi) continue;
+            const uint8_t *tag = lds + fld[c].text_off;
+            put_lds(dst, tag, nl + 2);
+            put_lds(dst + nl + 2 + len, tag + nl + 2, nl + 3);
+
+            // the value: aligned words of the arena, shifted into place
+            uint32_t k0, k1;
+            const uint64_t vp = dst + nl + 2;
+            clip(vp, len, k0, k1);
+            if (k0 < k1) {
+                const uint32_t a = ((fg_u32 *)offp[c])[r0 + i];
+                const uint64_t ga = (uint64_t)(bytp[c] + a + k0);
+                const uint32_t sh = (uint32_t)ga & 3;
+                fg_u32 *w = (fg_u32 *)(ga - sh);
+                const uint32_t n = k1 - k0;
+                const uint32_t nwords = (sh + n + 3) >> 2;
+                uint32_t s = (uint32_t)(vp - wlo) + k0;
+                uint32_t lo = w[0];
+                for (uint32_t j = 0; j * 4 < n; ++j) {
+                    const uint32_t hi = j + 1 < nwords ? w[j + 1] : 0;
+                    const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                    const uint32_t m = n - j * 4 < 4 ? n - j * 4 : 4;
+                    if (!EXACT) {
+                        uint32_t z = (v - 0x01010101u) & ~v & 0x80808080u;
+                        if (m < 4) z &= (1u << (8 * m)) - 1;
+                        sawcut |= z;
+                    }
+                    stage[s] = (uint8_t)v;
+                    if (m > 1) stage[s + 1] = (uint8_t)(v >> 8);
+                    if (m > 2) stage[s + 2] = (uint8_t)(v >> 16);
+                    if (m > 3) stage[s + 3] = (uint8_t)(v >> 24);
+                    s += 4;
+                    lo = hi;
+                }
+            }
+        }
+        __syncthreads();
+
+        const uint64_t lo = wlo > blk_lo ? wlo : blk_lo;
+        const uint64_t hi = whi < blk_hi ? whi : blk_hi;
+        for (uint32_t j = lane; j * 16 < STAGE; j += FMT_BLOCK) {
+            const uint64_t g = wlo + 16ull * j;
+            if (g >= hi) break;
+            if (g >= lo && g + 16 <= hi) {
+                *(fu32x4 *)(P.out + g) = *(const fu32x4 *)(stage + 16 * j);
+            } else {
+                for (uint32_t b = 0; b < 16; ++b)
+                    if (g + b >= lo && g + b < hi) P.out[g + b] = stage[16 * j + b];
+            }
+        }
+        __syncthreads();
+    }
+    if (!EXACT && sawcut) atomicOr(P.status, FS_NEED_EXACT);
+}
+
+// info[0] = sum of the columns' last offsets, info[1] = sum of their first offsets,
+// info[2] = 1 when a column's last offset passes the end of its arena (nbytes may be null)
+__global__ __launch_bounds__(128) void format_prep_kernel(const uint32_t *const *off, const uint64_t *nbytes,
+                                                          uint32_t ncols, uint64_t rows, uint64_t *info) {
+    __shared__ uint64_t first[128], last[128];
+    __shared__ uint32_t bad;
+    const uint32_t c = threadIdx.x;
+    if (c == 0) bad = 0;
+    __syncthreads();
+    first[c] = last[c] = 0;
+    if (c < ncols) {
+        first[c] = off[c][0];
+        last[c] = off[c][rows];
+        if (last[c] < first[c] || (nbytes && last[c] > nbytes[c])) bad = 1;
+    }
+    __syncthreads();
+    if (c == 0) {
+        uint64_t a = 0, b = 0;
+        for (uint32_t k = 0; k < ncols; ++k) {
+            a += last[k];
+            b += first[k];
+        }
+        info[0] = a;
+        info[1] = b;
+        info[2] = bad;
+    }
+}
+
+// exact mode, first step: the length "%s" prints of every value, and every record's length
+__global__ __launch_bounds__(256) void format_measure_kernel(const uint32_t *const *off, const uint8_t *const *bytes,
+                                                             const uint8_t *blob, uint32_t ncols, uint64_t rows,
+                                                             uint32_t fixed, uint32_t *elen, uint64_t *reclen,
+                                                             uint32_t *status) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const FormatField *fld = (const FormatField *)blob;
+    uint64_t run = fixed;
+    for (uint32_t c = 0; c < ncols; ++c) {
+        const uint32_t a = off[c][r], b = off[c][r + 1];
+        uint32_t n = b - a;
+        if (b < a) {
+            atomicOr(status, FS_BAD_OFFSETS);
+            n = 0;
+        }
+        const uint32_t fl = fld[c].fieldlen;
+        if (fl && n > fl) n = fl;
+        const uint8_t *p = bytes[c] + a;
+        for (uint32_t k = 0; k < n; ++k)
+            if (p[k] == 0) {
+                n = k;
+                break;
+            }
+        elen[(uint64_t)c * rows + r] = n;
+        run += n;
+    }
+    reclen[r] = run;
+}
+
+// ---- exclusive scan of u64 (record lengths -> record starts), three small kernels -------------
+constexpr uint32_t SCAN_ITEMS = 8; // per lane; 2048 per block
+
+__device__ __forceinline__ uint64_t block_exclusive(uint64_t v, uint64_t *wsum, uint64_t &total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < blockDim.x / 64; ++w) {
+        if (w < wave) base += wsum[w];
+        tot += wsum[w];
+    }
+    __syncthreads();
+    total = tot;
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(256) void scan64_sums(const uint64_t *in, uint64_t n, uint64_t *part) {
+    __shared__ uint64_t wsum[4];
+    const uint64_t b0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * SCAN_ITEMS;
+    uint64_t s = 0;
+    for (uint32_t k = 0; k < SCAN_ITEMS; ++k)
+        if (b0 + k < n) s += in[b0 + k];
+    uint64_t total;
+    block_exclusive(s, wsum, total);
+    if (threadIdx.x == 0) part[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void scan64_parts(uint64_t *part, uint32_t nparts) {
+    __shared__ uint64_t wsum[4];
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < nparts; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t v = i < nparts ? part[i] : 0;
+        uint64_t total;
+        const uint64_t e = block_exclusive(v, wsum, total);
+        if (i < nparts) part[i] = carry + e;
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(256) void scan64_apply(const uint64_t *in, uint64_t n, const uint64_t *part,
+                                                    uint64_t *out) {
+    __shared__ uint64_t wsum[4];
+    const uint64_t b0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS], s = 0;
+    for (uint32_t k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = b0 + k < n ? in[b0 + k] : 0;
+        s += v[k];
+    }
+    uint64_t total;
+    uint64_t e = part[blockIdx.x] + block_exclusive(s, wsum, total);
+    for (uint32_t k = 0; k < SCAN_ITEMS; ++k) {
+        if (b0 + k < n) out[b0 + k] = e;
+        e += v[k];
+        if (b0 + k + 1 == n) out[n] = e;
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------
+
+hipError_t launch_format_prep(const uint32_t *const *off, const uint64_t *nbytes, uint32_t ncols, uint64_t rows,
+                              uint64_t *info, hipStream_t stream) {
+    hipLaunchKernelGGL(format_prep_kernel, dim3(1), dim3(128), 0, stream, off, nbytes, ncols, rows, info);
+    return hipGetLastError();
+}
+
+hipError_t launch_format(bool exact, const FormatParams &P, hipStream_t stream) {
+    const uint64_t nblocks = (P.rows + P.R - 1) >> P.Rshift;
+    if (nblocks == 0 || nblocks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (exact)
+        hipLaunchKernelGGL(format_kernel<true>, dim3((uint32_t)nblocks), dim3(FMT_BLOCK), P.lds_total, stream, P);
+    else
+        hipLaunchKernelGGL(format_kernel<false>, dim3((uint32_t)nblocks), dim3(FMT_BLOCK), P.lds_total, stream, P);
+    return hipGetLastError();
+}
+
+uint32_t format_scan_parts(uint64_t rows) { return (uint32_t)((rows + 256 * SCAN_ITEMS - 1) / (256 * SCAN_ITEMS)); }
+
+// reclen[rows] -> recpos[rows+1]; part needs format_scan_parts(rows) entries
+hipError_t launch_format_measure(const FormatParams &P, uint32_t *elen, uint64_t *reclen, uint64_t *part,
+                                 uint64_t *recpos, hipStream_t stream) {
+    const uint64_t nb = (P.rows + 255) / 256;
+    if (nb == 0 || nb > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(format_measure_kernel, dim3((uint32_t)nb), dim3(256), 0, stream, P.off, P.bytes, P.blob,
+                       P.ncols, P.rows, P.fixed, elen, reclen, P.status);
+    const uint32_t np = format_scan_parts(P.rows);
+    hipLaunchKernelGGL(scan64_sums, dim3(np), dim3(256), 0, stream, reclen, P.rows, part);
+    hipLaunchKernelGGL(scan64_parts, dim3(1), dim3(256), 0, stream, part, np);
+    hipLaunchKernelGGL(scan64_apply, dim3(np), dim3(256), 0, stream, reclen, P.rows, part, recpos);
+    return hipGetLastError();
+}
+
+} // namespace mdc

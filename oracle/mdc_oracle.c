@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 /* ------------------------------------------------------------------ small helpers */
 
@@ -422,5 +423,116 @@ orc_batch *ORC_FN(parse_csv)(const uint8_t *data, size_t n, const char *sep, int
 }
 
 void ORC_FN(batch_free)(orc_batch *b) { builder_free(b); }
+
+/* ---- N1: writer side -------------------------------------------------------------------- */
+
+/* bytes "%s" prints of a fetched value: the fetch buffer holds at most fieldlen bytes and a
+ * terminating NUL (public/db/oracle/_ooci.cpp:622-627), c_str() ends at the first NUL
+ * (tools/dminingoracle.cpp:217-218) */
+static size_t value_len(const uint8_t *p, size_t n, int fieldlen) {
+    if (fieldlen > 0 && n > (size_t)fieldlen) n = (size_t)fieldlen;
+    const void *z = memchr(p, 0, n);
+    return z ? (size_t)((const uint8_t *)z - p) : n;
+}
+
+static void put(uint8_t *out, uint64_t *pos, const void *src, size_t n) {
+    if (out) memcpy(out + *pos, src, n);
+    *pos += n;
+}
+
+int64_t ORC_FN(format_xml)(const char *const *fieldname, const int *fieldlen, int nfields,
+                           const uint32_t *const *off, const uint8_t *const *bytes, int64_t rows,
+                           int64_t maxcount, uint8_t *out, uint64_t *file_off, int64_t filecap,
+                           int64_t *nfiles) {
+    uint64_t pos = 0;
+    int64_t files = 0, rpc = 0;
+    int isopen = 0;
+    for (int64_t r = 0; r < rows; ++r) { /* while (stmtsel.next()==0), :200 */
+        ++rpc;
+        if (!isopen) {                   /* :202-213 */
+            if (file_off && files < filecap) file_off[files] = pos;
+            ++files;
+            isopen = 1;
+            put(out, &pos, "<data>\n", 7);
+        }
+        for (int i = 0; i < nfields; ++i) { /* :216-218 */
+            size_t nl = strlen(fieldname[i]);
+            const uint8_t *v = bytes[i] + off[i][r];
+            size_t vl = value_len(v, off[i][r + 1] - off[i][r], fieldlen ? fieldlen[i] : 0);
+            put(out, &pos, "<", 1);
+            put(out, &pos, fieldname[i], nl);
+            put(out, &pos, ">", 1);
+            put(out, &pos, v, vl);
+            put(out, &pos, "</", 2);
+            put(out, &pos, fieldname[i], nl);
+            put(out, &pos, ">", 1);
+        }
+        put(out, &pos, "<endl/>\n", 8); /* :219 */
+        if (maxcount > 0 && rpc % maxcount == 0) { /* :222-233 */
+            put(out, &pos, "</data>\n", 8);
+            isopen = 0;
+        }
+    }
+    if (maxcount == 0 || rpc % maxcount > 0) { /* :241-256 */
+        if (!isopen) return -1;                /* writeline and closeandrename fail */
+        put(out, &pos, "</data>\n", 8);
+        isopen = 0;
+    }
+    if (file_off && files < filecap) file_off[files] = pos;
+    if (nfiles) *nfiles = files;
+    return (int64_t)pos;
+}
+
+/* create the directories above a file name (newdir(name,true), public/_public.cpp:952-980) */
+static void make_parents(const char *path) {
+    char tmp[4096];
+    size_t n = strlen(path);
+    if (n >= sizeof tmp) return;
+    memcpy(tmp, path, n + 1);
+    for (size_t i = 1; i < n; ++i)
+        if (tmp[i] == '/') {
+            tmp[i] = 0;
+            mkdir(tmp, 0755);
+            tmp[i] = '/';
+        }
+}
+
+int64_t ORC_FN(format_xml_files)(const char *const *fieldname, const int *fieldlen, int nfields,
+                                 const uint32_t *const *off, const uint8_t *const *bytes,
+                                 int64_t rows, int64_t maxcount, const char *outpath,
+                                 const char *bfilename, const char *timestamp,
+                                 const char *efilename, int first_seq) {
+    int64_t nfiles = 0;
+    int64_t total = ORC_FN(format_xml)(fieldname, fieldlen, nfields, off, bytes, rows, maxcount, NULL,
+                                       NULL, 0, &nfiles);
+    if (total < 0) return -1;
+    uint8_t *buf = (uint8_t *)malloc((size_t)total + 1);
+    uint64_t *fo = (uint64_t *)malloc((size_t)(nfiles + 1) * sizeof(uint64_t));
+    if (!buf || !fo) {
+        free(buf);
+        free(fo);
+        return -1;
+    }
+    ORC_FN(format_xml)(fieldname, fieldlen, nfields, off, bytes, rows, maxcount, buf, fo, nfiles + 1,
+                       &nfiles);
+    int64_t done = 0;
+    for (int64_t k = 0; k < nfiles; ++k) {
+        char name[4096], tmp[4200];
+        snprintf(name, sizeof name, "%s/%s_%s_%s_%d.xml", outpath, bfilename, timestamp, efilename,
+                 first_seq + (int)k); /* :204-205 */
+        snprintf(tmp, sizeof tmp, "%s.tmp", name);
+        make_parents(name);
+        FILE *f = fopen(tmp, "wb");
+        if (!f) break;
+        size_t len = (size_t)(fo[k + 1] - fo[k]);
+        int ok = fwrite(buf + fo[k], 1, len, f) == len;
+        ok = (fclose(f) == 0) && ok;
+        if (!ok || rename(tmp, name) != 0) break;
+        ++done;
+    }
+    free(buf);
+    free(fo);
+    return done == nfiles ? nfiles : -1;
+}
 
 const char *ORC_FN(kind)(void) { return "port"; }

@@ -107,6 +107,30 @@ orc_batch *ORC_FN(parse_xml_file)(const char *path, const char *endbz, const orc
 orc_batch *ORC_FN(parse_csv)(const uint8_t *data, size_t n, const char *sep, int bdelspace,
                              int nfields, const int *ilen, const int *typed);
 
+/* N1  writer side: the record formatter of tools/dminingoracle.cpp:196-256.  For every row the
+ * fields are written as "<name>value</name>" (value = the cell as a C string: cut at its first
+ * NUL, and at fieldlen[c] bytes when fieldlen[c]>0, which is what the fetch buffer of
+ * sqlstatement::bindout(pos,string&,len) can hold, public/db/oracle/_ooci.cpp:622-627), then
+ * "<endl/>\n"; a file starts with "<data>\n", ends with "</data>\n" and is closed after every
+ * maxcount rows (maxcount 0: one file).  All files are laid back to back into out (NULL to
+ * size only); file k is [file_off[k], file_off[k+1]) (file_off may be NULL, else holds
+ * *nfiles+1 entries, at most filecap).  Returns the total length, or -1 where the reference
+ * fails: no rows and maxcount 0 (closeandrename on a file never opened, :241-248). */
+int64_t ORC_FN(format_xml)(const char *const *fieldname, const int *fieldlen, int nfields,
+                           const uint32_t *const *off, const uint8_t *const *bytes, int64_t rows,
+                           int64_t maxcount, uint8_t *out, uint64_t *file_off, int64_t filecap,
+                           int64_t *nfiles);
+
+/* same, written to disk the way cofile does (name + ".tmp", renamed on close; missing
+ * directories created; public/_public.cpp:894-940) under the names of
+ * tools/dminingoracle.cpp:204-205, "%s/%s_%s_%s_%d.xml" with the time stamp passed in and the
+ * sequence number starting at first_seq.  Returns the number of files, -1 on failure. */
+int64_t ORC_FN(format_xml_files)(const char *const *fieldname, const int *fieldlen, int nfields,
+                                 const uint32_t *const *off, const uint8_t *const *bytes,
+                                 int64_t rows, int64_t maxcount, const char *outpath,
+                                 const char *bfilename, const char *timestamp,
+                                 const char *efilename, int first_seq);
+
 void ORC_FN(batch_free)(orc_batch *b);
 
 /* name of the implementation behind this library */

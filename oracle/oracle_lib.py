@@ -109,6 +109,10 @@ class Checker:
         f("parse_xml_file").argtypes = [ctypes.c_char_p, ctypes.c_char_p, vp, ci, vp, ci]
         f("parse_csv").restype = pb
         f("parse_csv").argtypes = [vp, sz, ctypes.c_char_p, ci, ci, vp, vp]
+        f("format_xml").restype = i64
+        f("format_xml").argtypes = [vp, vp, ci, vp, vp, i64, i64, vp, vp, i64, ctypes.POINTER(i64)]
+        f("format_xml_files").restype = i64
+        f("format_xml_files").argtypes = [vp, vp, ci, vp, vp, i64, i64] + [ctypes.c_char_p] * 4 + [ci]
         f("batch_free").restype = None
         f("batch_free").argtypes = [pb]
         f("kind").restype = ctypes.c_char_p
@@ -188,6 +192,41 @@ class Checker:
         ty = (ctypes.c_int * max(1, nfields))(*typed) if typed is not None else None
         pb = self._f("parse_csv")(buf.ctypes.data if buf.size else None, buf.size, sep.encode(), int(bdelspace), nfields, il, ty)
         return self._take(pb, typed)
+
+
+    # -- writer side --------------------------------------------------------------------
+    @staticmethod
+    def _columns(names, fieldlen, off, data):
+        n = len(names)
+        enc = [nm.encode() if isinstance(nm, str) else bytes(nm) for nm in names]
+        c_names = (ctypes.c_char_p * max(1, n))(*enc)
+        c_len = (ctypes.c_int * max(1, n))(*fieldlen) if fieldlen is not None else None
+        offs = [np.ascontiguousarray(o, dtype=np.uint32) for o in off]
+        dats = [np.ascontiguousarray(d, dtype=np.uint8) if len(d) else np.zeros(1, np.uint8) for d in data]
+        c_off = (ctypes.c_void_p * max(1, n))(*[o.ctypes.data for o in offs])
+        c_dat = (ctypes.c_void_p * max(1, n))(*[d.ctypes.data for d in dats])
+        return c_names, c_len, c_off, c_dat, (enc, offs, dats)
+
+    def format_xml(self, names, off, data, rows: int, maxcount: int = 0, fieldlen=None):
+        """All files back to back and their offsets, or None where the reference fails."""
+        c_names, c_len, c_off, c_dat, keep = self._columns(names, fieldlen, off, data)
+        nf = ctypes.c_int64(0)
+        fn = self._f("format_xml")
+        total = fn(c_names, c_len, len(names), c_off, c_dat, rows, maxcount, None, None, 0, ctypes.byref(nf))
+        if total < 0:
+            return None
+        out = np.zeros(max(total, 1), dtype=np.uint8)
+        fo = np.zeros(nf.value + 1, dtype=np.uint64)
+        fn(c_names, c_len, len(names), c_off, c_dat, rows, maxcount, out.ctypes.data, fo.ctypes.data,
+           nf.value + 1, ctypes.byref(nf))
+        return out[:total], fo
+
+    def format_xml_files(self, names, off, data, rows: int, maxcount: int, outpath: str, bfilename: str,
+                         timestamp: str, efilename: str, first_seq: int = 1, fieldlen=None) -> int:
+        c_names, c_len, c_off, c_dat, keep = self._columns(names, fieldlen, off, data)
+        return self._f("format_xml_files")(c_names, c_len, len(names), c_off, c_dat, rows, maxcount,
+                                           outpath.encode(), bfilename.encode(), timestamp.encode(),
+                                           efilename.encode(), first_seq)
 
 
 _cache = {}

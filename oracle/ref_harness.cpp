@@ -302,6 +302,86 @@ orc_batch *ref_parse_csv(const uint8_t *data, size_t n, const char *sep, int bde
     return b;
 }
 
+/* The fetch loop of _dminingoracle (tools/dminingoracle.cpp:196-256) with the row source
+ * replaced by columns in memory: dminingoracle.cpp itself needs the OCI headers.  The file
+ * writing is the reference's own cofile (open / writeline / closeandrename) and sformat; the
+ * restated part is the loop around them and the fetch of one row into fieldvalue[], which
+ * stands in for OCIStmtFetch into the buffers of bindout(pos,string&,len)
+ * (public/db/oracle/_ooci.cpp:622-627: resize(len), at most len bytes and a NUL). */
+int64_t ref_format_xml_files(const char *const *fieldname, const int *fieldlen, int nfields,
+                             const uint32_t *const *off, const uint8_t *const *bytes, int64_t rows,
+                             int64_t maxcount, const char *outpath, const char *bfilename,
+                             const char *timestamp, const char *efilename, int first_seq) {
+    std::vector<std::string> fieldvalue(nfields);
+    cofile ofile;
+    std::string xmlfile;
+    int iseq = first_seq;
+    int64_t rpc = 0, nfiles = 0;
+
+    for (int64_t r = 0; r < rows; ++r) {
+        ++rpc; /* stmtsel.next()==0 fetched one more row */
+        for (int i = 0; i < nfields; ++i) {
+            size_t n = off[i][r + 1] - off[i][r];
+            size_t cap = fieldlen && fieldlen[i] > 0 ? (size_t)fieldlen[i] : n;
+            fieldvalue[i].assign(cap + 1, '\0');
+            memcpy(&fieldvalue[i][0], bytes[i] + off[i][r], n < cap ? n : cap);
+        }
+        if (ofile.isopen() == false) {
+            sformat(xmlfile, "%s/%s_%s_%s_%d.xml", outpath, bfilename, timestamp, efilename, iseq++);
+            if (ofile.open(xmlfile) == false) return -1;
+            ++nfiles;
+            ofile.writeline("<data>\n");
+        }
+        for (int i = 0; i < nfields; ++i)
+            ofile.writeline("<%s>%s</%s>", fieldname[i], fieldvalue[i].c_str(), fieldname[i]);
+        ofile.writeline("<endl/>\n");
+        if ((maxcount > 0) && (rpc % maxcount == 0)) {
+            ofile.writeline("</data>\n");
+            if (ofile.closeandrename() == false) return -1;
+        }
+    }
+    if ((maxcount == 0) || (rpc % maxcount > 0)) {
+        ofile.writeline("</data>\n");
+        if (ofile.closeandrename() == false) return -1;
+    }
+    return nfiles;
+}
+
+/* in memory: written through cofile into a scratch directory and read back */
+int64_t ref_format_xml(const char *const *fieldname, const int *fieldlen, int nfields,
+                       const uint32_t *const *off, const uint8_t *const *bytes, int64_t rows,
+                       int64_t maxcount, uint8_t *out, uint64_t *file_off, int64_t filecap,
+                       int64_t *nfiles) {
+    const char *base = getenv("TMPDIR");
+    std::string dir = std::string(base && *base ? base : "/tmp") + "/mdc_fmt_XXXXXX";
+    if (!mkdtemp(&dir[0])) return -1;
+    int64_t nf = ref_format_xml_files(fieldname, fieldlen, nfields, off, bytes, rows, maxcount,
+                                      dir.c_str(), "b", "t", "e", 1);
+    uint64_t pos = 0;
+    for (int64_t k = 0; k < (nf < 0 ? 0 : nf); ++k) {
+        std::string name = dir + "/b_t_e_" + std::to_string(k + 1) + ".xml";
+        if (file_off && k < filecap) file_off[k] = pos;
+        FILE *f = fopen(name.c_str(), "rb");
+        if (f) {
+            char buf[65536];
+            size_t got;
+            while ((got = fread(buf, 1, sizeof buf, f)) > 0) {
+                if (out) memcpy(out + pos, buf, got);
+                pos += got;
+            }
+            fclose(f);
+        }
+        unlink(name.c_str());
+    }
+    /* a failed run leaves its .tmp behind, as the reference does */
+    unlink((dir + "/b_t_e_1.xml.tmp").c_str());
+    rmdir(dir.c_str());
+    if (nf < 0) return -1;
+    if (file_off && nf < filecap) file_off[nf] = pos;
+    if (nfiles) *nfiles = nf;
+    return (int64_t)pos;
+}
+
 void ref_batch_free(orc_batch *b) { builder_free(b); }
 
 const char *ref_kind(void) { return "reference"; }

@@ -266,3 +266,74 @@ def probe_csv() -> List[Tuple[str, bytes, str, bool]]:
         ("unterminated_tail", b"1,2\n3,4", ",", False),
         ("space_sep", b"a  b c\n", " ", False),
     ]
+
+
+# ---- writer side ---------------------------------------------------------------------------
+# field lists of the extractor's own usage text (tools/dminingoracle.cpp:350, :357)
+CODE_FIELDS = (["obtid", "cityname", "provname", "lat", "lon", "height"], [5, 30, 30, 10, 10, 10])
+MIND_FIELDS = (["obtid", "ddatetime", "t", "p", "u", "wd", "wf", "r", "vis", "keyid"],
+               [5, 19, 8, 8, 8, 8, 8, 8, 8, 15])
+
+
+def columns_of(rows_of_cells: Sequence[Sequence[bytes]], nfields: int):
+    """rows of cells -> per column (u32 offsets, byte arena), the layout of a parsed batch"""
+    import numpy as np
+    off, data = [], []
+    for c in range(nfields):
+        cells = [bytes(r[c]) for r in rows_of_cells]
+        o = np.zeros(len(cells) + 1, dtype=np.uint32)
+        if cells:
+            o[1:] = np.cumsum([len(x) for x in cells])
+        off.append(o)
+        data.append(np.frombuffer(b"".join(cells), dtype=np.uint8).copy())
+    return off, data
+
+
+def random_rows(seed: int, nrows: int, nfields: int, maxlen: int = 12, nul: float = 0.0, big: float = 0.0):
+    rng = random.Random(seed)
+    alphabet = b"0123456789.-abcXYZ <>/%\xe4\xb8\xad"
+    rows = []
+    for _ in range(nrows):
+        row = []
+        for _ in range(nfields):
+            n = rng.randrange(0, maxlen + 1)
+            if big and rng.random() < big:
+                n = rng.randrange(maxlen, 40 * maxlen)
+            cell = bytearray(rng.choice(alphabet) for _ in range(n))
+            if nul and n and rng.random() < nul:
+                cell[rng.randrange(n)] = 0
+            row.append(bytes(cell))
+        rows.append(row)
+    return rows
+
+
+def format_cases():
+    """(name, fieldnames, fieldlen or None, rows of cells, maxcount)"""
+    out = []
+    mind_rows = [[b"58015", b"2024-05-19 16:28:00", b"12.7", b"1013.2", b"65", b"180", b"3.4", b"0.0",
+                  b"10000.5", str(1000 + i).encode()] for i in range(7)]
+    mind_rows[3][2] = b"-40.0"
+    mind_rows[5][8] = b""
+    for mc in (0, 1, 3, 7, 1000):
+        out.append((f"mind/maxcount={mc}", MIND_FIELDS[0], MIND_FIELDS[1], mind_rows, mc))
+    code_rows = [[b"58015", "砀山".encode(), "安徽".encode(), b"34.27", b"116.2", b"44.2"],
+                 [b"58102", "亳州".encode(), "安徽".encode(), b"33.47", b"115.44", b"39.1"],
+                 [b"58118", "蒙城".encode(), "安徽".encode(), b"33.16", b"116.31", b"27"]]
+    out.append(("code/maxcount=2", CODE_FIELDS[0], CODE_FIELDS[1], code_rows, 2))
+    cut_rows = [[b"abcdefgh", b"12\x0034", b""], [b"\x00", b"x" * 40, b"tail\x00"], [b"ab", b"", b"\x00\x00"],
+                [b"abcd", b"abcde", b"abcdef"]]
+    out.append(("cuts/fieldlen", ["a", "bb", "ccc"], [4, 10, 5], cut_rows, 0))
+    out.append(("cuts/nul_only", ["a", "bb", "ccc"], None, cut_rows, 3))
+    out.append(("cuts/fieldlen_some", ["a", "bb", "ccc"], [0, 3, 0], cut_rows, 2))
+    out.append(("one_field_one_row", ["v"], None, [[b"1"]], 0))
+    out.append(("empty_cells", ["a", "b"], None, [[b"", b""], [b"", b""]], 1))
+    out.append(("zero_rows/maxcount=0", ["a", "b"], None, [], 0))
+    out.append(("zero_rows/maxcount=5", ["a", "b"], None, [], 5))
+    out.append(("odd_names", ["a b", "x<y", "%s%d", "中文", "e" * 40], None,
+                [[b"%s", b"%n%n", b"<a b>", b"</x<y>", b"<endl/>"], [b"1", b"2", b"3", b"4", b"5"]], 0))
+    for seed in range(4):
+        nf = 1 + 3 * seed
+        fl = None if seed % 2 == 0 else [(3 * i) % 7 for i in range(nf)]
+        out.append((f"random/{seed}", [f"f{i}" * (1 + i % 3) for i in range(nf)], fl,
+                    random_rows(seed, 23 + seed, nf, nul=0.1 * (seed % 3), big=0.05 * seed), [0, 5, 23, 4][seed]))
+    return out

@@ -109,7 +109,17 @@ def main():
         scalar["getxmlbuffer"].append({"rec": rec.hex(), "name": name, "ilen": ilen,
                                        "out": v.hex() if ok else None})
 
-    for fn, obj in (("xml_cases.json", xml), ("csv_cases.json", csv), ("scalar_cases.json", scalar)):
+    fmt = []
+    for name, names, fieldlen, rows, maxcount in cases.format_cases():
+        off, data = cases.columns_of(rows, len(names))
+        r = ref.format_xml(names, off, data, len(rows), maxcount, fieldlen=fieldlen)
+        fmt.append({"name": name, "fieldname": names, "fieldlen": fieldlen, "maxcount": maxcount,
+                    "cells": [[c.hex() for c in row] for row in rows],
+                    "expect": None if r is None else {"text": base64.b64encode(bytes(r[0])).decode(),
+                                                      "file_off": [int(x) for x in r[1]]}})
+
+    for fn, obj in (("xml_cases.json", xml), ("csv_cases.json", csv), ("scalar_cases.json", scalar),
+                    ("format_cases.json", fmt)):
         with open(os.path.join(HERE, fn), "w") as f:
             json.dump(obj, f, indent=0, separators=(",", ":"))
         print(fn, os.path.getsize(os.path.join(HERE, fn)))

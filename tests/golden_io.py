@@ -63,3 +63,15 @@ def csv_cases():
 
 def scalar_cases():
     return _load("scalar_cases.json")
+
+
+def format_cases():
+    """Writer side: rows of cells and the text the reference's cofile wrote for them (None = it fails)."""
+    out = []
+    for c in _load("format_cases.json"):
+        rows = [[bytes.fromhex(x) for x in row] for row in c["cells"]]
+        e = c["expect"]
+        out.append(dict(name=c["name"], names=c["fieldname"], fieldlen=c["fieldlen"], maxcount=c["maxcount"],
+                        rows=rows, text=None if e is None else base64.b64decode(e["text"]),
+                        file_off=None if e is None else e["file_off"]))
+    return out

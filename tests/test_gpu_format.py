@@ -1,0 +1,241 @@
+"""GPU parity of the writer side: the formatting kernels, called through the C ABI of
+include/mdc_format.h, against the CPU checker and the golden texts.  Byte-exact."""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import golden_io
+from dsp_amd import capi, gen, schema
+from dsp_amd.schema import Col
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_format(names, fieldlen, off, data, rows, maxcount):
+    f = capi.Formatter(names, fieldlen)
+    try:
+        t = f.format_host(off, data, rows, maxcount)
+        out = (t.host(), t.file_off(), f.timing().exact_pass)
+        # the same formatter again: workspace reuse must not change a byte
+        t2 = f.format_host(off, data, rows, maxcount)
+        assert np.array_equal(t2.host(), out[0]) and np.array_equal(t2.file_off(), out[1])
+        t.free()
+        t2.free()
+        return out
+    finally:
+        f.close()
+
+
+def check_against(port, names, fieldlen, rows, maxcount, what, expect_exact=None):
+    off, data = cases.columns_of(rows, len(names))
+    print("format", what, "rows", len(rows), "fields", len(names), "maxcount", maxcount, flush=True)
+    exp = port.format_xml(names, off, data, len(rows), maxcount, fieldlen=fieldlen)
+    text, fo, exact = gpu_format(names, fieldlen, off, data, len(rows), maxcount)
+    if exp is None:  # the reference fails only where there are no rows; the text is then empty
+        assert len(rows) == 0 and text.size == 0 and list(fo) == [0]
+        return
+    assert bytes(text) == bytes(exp[0]), what
+    assert list(fo) == list(exp[1]), what
+    if expect_exact is not None:
+        assert exact == expect_exact, what
+
+
+@pytest.mark.parametrize("case", golden_io.format_cases(), ids=lambda c: c["name"])
+def test_golden_format(case):
+    off, data = cases.columns_of(case["rows"], len(case["names"]))
+    print("golden", case["name"], flush=True)
+    text, fo, _ = gpu_format(case["names"], case["fieldlen"], off, data, len(case["rows"]), case["maxcount"])
+    if case["text"] is None:
+        assert text.size == 0 and list(fo) == [0]
+    else:
+        assert bytes(text) == case["text"]
+        assert [int(x) for x in fo] == case["file_off"]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_columns(port, seed):
+    nf = [1, 2, 5, 11, 17, 3, 64, 128][seed]
+    rows = cases.random_rows(300 + seed, [1, 2, 63, 64, 65, 1000, 257, 130][seed], nf, maxlen=3 + 2 * seed)
+    names = [("c%d" % i) * (1 + (i + seed) % 3) for i in range(nf)]
+    for mc in (0, 1, 7, 64, len(rows)):
+        check_against(port, names, None, rows, mc, f"random {seed}", expect_exact=0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_values_that_need_cutting(port, seed):
+    nf = 1 + seed
+    rows = cases.random_rows(400 + seed, 500 + 100 * seed, nf, maxlen=10, nul=[0.001, 0.02, 0.3, 0, 0, 0.1][seed])
+    names = ["f%d" % i for i in range(nf)]
+    fl = None if seed < 3 else [(4 + i) if i % 2 == 0 else 0 for i in range(nf)]
+    cut = any(b"\0" in cell or (fl and fl[c] and len(cell) > fl[c]) for row in rows for c, cell in enumerate(row))
+    assert cut or seed == 0
+    for mc in (0, 33):
+        check_against(port, names, fl, rows, mc, f"cut {seed}", expect_exact=int(cut))
+
+
+def test_fieldlen_that_never_cuts_keeps_the_single_pass(port):
+    rows = cases.random_rows(7, 300, 3, maxlen=6)
+    check_against(port, ["a", "b", "c"], [6, 7, 100], rows, 0, "loose fieldlen", expect_exact=0)
+
+
+def test_long_values_span_several_staging_windows(port):
+    rng = np.random.default_rng(3)
+    rows = []
+    for r in range(40):
+        big = bytes(rng.integers(1, 256, size=int(rng.integers(0, 70000)), dtype=np.uint8)) if r % 5 == 0 else b"x"
+        rows.append([b"%d" % r, big, b"tail"])
+    check_against(port, ["id", "blob", "t"], None, rows, 0, "long values", expect_exact=0)
+    check_against(port, ["id", "blob", "t"], None, rows, 7, "long values", expect_exact=0)
+    check_against(port, ["id", "blob", "t"], [0, 1000, 0], rows, 3, "long values cut", expect_exact=1)
+
+
+def test_longest_names_and_most_fields(port):
+    names = [("n%03d" % i) + "x" * 40 for i in range(128)]
+    rows = cases.random_rows(11, 70, 128, maxlen=4)
+    check_against(port, names, None, rows, 9, "128 fields")
+    check_against(port, ["y" * 255, "z"], None, cases.random_rows(12, 300, 2, maxlen=9), 0, "255-byte name")
+
+
+def test_device_columns_with_a_nonzero_first_offset(port):
+    """mdc_format_device on a window of rows inside larger columns: offsets need not start at 0."""
+    nf, total, lo, hi = 4, 900, 123, 777
+    rows = cases.random_rows(21, total, nf, maxlen=9)
+    off, data = cases.columns_of(rows, nf)
+    names = ["a", "bb", "ccc", "dddd"]
+    bufs_o = [capi.DeviceBuffer(o.view(np.uint8)) for o in off]
+    bufs_d = [capi.DeviceBuffer(d if d.size else np.zeros(1, np.uint8)) for d in data]
+    f = capi.Formatter(names)
+    try:
+        for mc in (0, 50):
+            t = f.format_device([b.ptr + 4 * lo for b in bufs_o], [b.ptr for b in bufs_d], hi - lo, mc)
+            so, sd = cases.columns_of(rows[lo:hi], nf)
+            exp = port.format_xml(names, so, sd, hi - lo, mc)
+            assert bytes(t.host()) == bytes(exp[0])
+            assert list(t.file_off()) == list(exp[1])
+            t.free()
+    finally:
+        f.close()
+        for b in bufs_o + bufs_d:
+            b.free()
+
+
+def test_descending_offsets_are_refused():
+    f = capi.Formatter(["a"])
+    try:
+        off = [np.array([0, 5, 3, 8], dtype=np.uint32)]
+        data = [np.frombuffer(b"abcdefgh", dtype=np.uint8)]
+        with pytest.raises(capi.MdcError) as e:
+            f.format_host(off, data, 3, 0)
+        assert e.value.code == capi.MDC_ERR_ARG
+    finally:
+        f.close()
+
+
+def test_parsed_batch_formats_and_parses_back(port):
+    """format(parse(x)) through mdc_format_batch (columns never leave HBM), and parse of that text
+    gives the same columns again."""
+    cols = schema.ZHOBTMIND
+    data, _ = gen.mind_xml(rows=5000)
+    names = [c.colname for c in cols]
+    p = capi.Parser.xml(cols)
+    f = capi.Formatter(names)
+    try:
+        b = p.parse_host(data)
+        hb = b.to_host()
+        for mc in (0, 1000, 777):
+            t = f.format_batch(b, mc)
+            exp = port.format_xml(names, hb.off, hb.data, hb.rows, mc)
+            assert bytes(t.host()) == bytes(exp[0])
+            assert list(t.file_off()) == list(exp[1])
+            assert f.timing().exact_pass == 0
+            d_ptr, n = t.device()
+            back = p.parse_device(d_ptr, n).to_host()
+            assert back.rows == hb.rows
+            for c in range(len(cols)):
+                assert np.array_equal(back.off[c], hb.off[c]) and np.array_equal(back.data[c], hb.data[c]), c
+            t.free()
+        b.free()
+    finally:
+        f.close()
+        p.close()
+
+
+def test_files_on_disk_match_the_checker(port, tmp_path):
+    names, fl = cases.MIND_FIELDS
+    rows = cases.random_rows(31, 2500, len(names), maxlen=8)
+    off, data = cases.columns_of(rows, len(names))
+    n_exp = port.format_xml_files(names, off, data, len(rows), 1000, str(tmp_path / "cpu" / "out"), "ZHOBTMIND",
+                                  "20240519162835", "togxpt", fieldlen=fl)
+    f = capi.Formatter(names, fl)
+    try:
+        t = f.format_host(off, data, len(rows), 1000)
+        n = t.write_files(str(tmp_path / "gpu" / "out"), "ZHOBTMIND", "togxpt", timestamp="20240519162835")
+        assert n == n_exp == 3
+        a = sorted(glob.glob(str(tmp_path / "gpu" / "out" / "*")))
+        b = sorted(glob.glob(str(tmp_path / "cpu" / "out" / "*")))
+        assert [os.path.basename(x) for x in a] == [os.path.basename(x) for x in b]
+        for x, y in zip(a, b):
+            assert open(x, "rb").read() == open(y, "rb").read()
+        # a stamp of the library's own: 14 digits
+        n = t.write_files(str(tmp_path / "now"), "B", "E", first_seq=5)
+        made = sorted(os.path.basename(x) for x in glob.glob(str(tmp_path / "now" / "*")))
+        assert n == 3 and len(made) == 3 and all(m.startswith("B_") and m.split("_")[1].isdigit()
+                                                  and len(m.split("_")[1]) == 14 for m in made)
+        assert sorted(m.split("_")[3] for m in made) == ["5.xml", "6.xml", "7.xml"]
+        t.free()
+        # no rows: nothing to write; with maxcount 0 the reference fails at this point
+        t0 = f.format_host(off, data, 0, 1000)
+        assert t0.files == 0 and t0.write_files(str(tmp_path / "none"), "B", "E") == 0
+        t1 = f.format_host(off, data, 0, 0)
+        with pytest.raises(capi.MdcError) as e:
+            t1.write_files(str(tmp_path / "none"), "B", "E")
+        assert e.value.code == capi.MDC_ERR_IO
+        assert not os.path.exists(tmp_path / "none")
+    finally:
+        f.close()
+
+
+def test_full_size_text_has_the_closed_form_length_and_parses_back():
+    """1 GiB of ZHOBTMIND records: parse, format in files of 1000 rows, parse the text again."""
+    cols = schema.ZHOBTMIND
+    names = [c.colname for c in cols]
+    data, rows = gen.mind_xml(nbytes=1 << 30)
+    buf = capi.DeviceBuffer(data)
+    p = capi.Parser.xml(cols, flags=capi.MDC_F_NO_RECOFF)
+    f = capi.Formatter(names)
+    try:
+        print("full size: parse", data.size, flush=True)
+        b = p.parse_device(buf.ptr, buf.n)
+        assert b.rows == rows
+        print("full size: format", flush=True)
+        t = f.format_batch(b, 1000)
+        tm = f.timing()
+        nfiles = (rows + 999) // 1000
+        cells = sum(b.device_column(c)[2] for c in range(len(cols)))
+        fixed = sum(2 * len(n) + 5 for n in names) + 8
+        assert t.files == nfiles
+        assert t.nbytes == rows * fixed + cells + 15 * nfiles == tm.bytes_out
+        fo = t.file_off()
+        assert fo[0] == 0 and fo[-1] == t.nbytes and np.all(np.diff(fo.astype(np.int64)) > 0)
+        buf.free()
+        d_ptr, n = t.device()
+        print("full size: parse the text", n, flush=True)
+        back = p.parse_device(d_ptr, n)
+        assert back.rows == rows
+        for c in (0, 2, 10):
+            o1, d1 = b.column(c)
+            o2, d2 = back.column(c)
+            assert np.array_equal(o1, o2) and np.array_equal(d1, d2), c
+        # every file starts and ends with its frame
+        text_head = t.host()[: int(fo[1])]
+        assert bytes(text_head[:7]) == b"<data>\n" and bytes(text_head[-8:]) == b"</data>\n"
+        back.free()
+        t.free()
+        b.free()
+    finally:
+        f.close()
+        p.close()
