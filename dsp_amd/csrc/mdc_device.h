@@ -144,14 +144,16 @@ constexpr uint32_t FS_BAD_OFFSETS = 2; // a column's offsets descend or pass the
 
 constexpr int FMT_BLOCK = 256;
 
-// Field table at the head of the formatter's blob, one entry per field; the tag text follows:
-// "<name>" at text_off, "</name>" right after it.  The blob ends with the 23 bytes
-// "<endl/>\n</data>\n<data>\n" at FormatParams::const_off.
+// Field table at the head of the formatter's blob, one entry per field; texts follow, each
+// 16-aligned and readable up to the next multiple of 16.  A field's text is what stands between
+// its value and the next one: "</name><next>", after the last field "</name><endl/>\n</data>\n"
+// (join_len stops before "</data>\n").  Two more texts open a row: "<first>" at
+// FormatParams::pre_plain_off and "<data>\n<first>" at pre_open_off.
 struct FormatField {
     uint32_t text_off;
     uint32_t name_len;
     uint32_t fieldlen; // 0 = no cut
-    uint32_t pad;
+    uint32_t join_len;
 };
 
 struct FormatParams {
@@ -159,7 +161,7 @@ struct FormatParams {
     const uint8_t *const *bytes; // device array [ncols] -> arenas
     const uint8_t *blob;
     uint32_t blob_bytes;         // multiple of 16
-    uint32_t const_off;
+    uint32_t pre_plain_off, pre_open_off;
     uint32_t ncols;
     uint32_t R, Rshift;          // records per block, a power of two <= FMT_BLOCK
     uint32_t fixed;              // bytes of a record that are not values: tags and "<endl/>\n"
@@ -173,7 +175,8 @@ struct FormatParams {
     const uint32_t *elen;        // [ncols][rows] value lengths after the cuts
     const uint64_t *recpos;      // [rows+1] record starts, file framing not counted
     // LDS regions (byte offsets)
-    uint32_t lds_ptrs, lds_cpos, lds_rstart, lds_rflag, lds_misc, lds_stage, stage_cap, lds_total;
+    uint32_t debug;              // diagnostic builds only: parts to skip (ablation timing)
+    uint32_t lds_ptrs, lds_cpos, lds_src, lds_rstart, lds_rflag, lds_misc, lds_stage, stage_cap, lds_total;
 };
 
 }  // namespace mdc

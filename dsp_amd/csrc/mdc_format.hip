@@ -18,6 +18,12 @@
 
 namespace mdc {
 
+#ifdef MDC_ABLATE
+#define FSKIP(bit) (P.debug & (bit)) // timing experiments only: 1 value words, 2 stores, 4 pieces
+#else
+#define FSKIP(bit) false
+#endif
+
 typedef __attribute__((address_space(1))) const uint8_t fg_u8;
 typedef __attribute__((address_space(1))) const uint32_t fg_u32;
 typedef uint32_t fu32x4 __attribute__((ext_vector_type(4)));
@@ -48,18 +54,37 @@ __device__ __forceinline__ FilePos file_pos(uint64_t r, uint64_t m, uint64_t row
     return f;
 }
 
+constexpr int UPL = 4; // (field, row) units per lane whose value words are fetched ahead
+constexpr int PW = 5;  // words fetched ahead per unit: values of up to 4 * PW - 3 bytes
+
+// A row's text is cut into one piece per field: the value and the constant text up to the next
+// value, "</name><next>" (after the last field "</name><endl/>\n", and "</data>\n" where the row
+// closes a file); the first field's piece starts with "<name>" (after "<data>\n" where the row
+// opens a file).  A piece belongs to one lane, which may therefore write whole words and let a
+// later write of its own cover the overrun; only the piece's last word is cut to the byte.
+//
+// Phases of a block (R rows, a power of two; unit u = (field u >> Rshift, row u & (R - 1))):
+//   1  every lane, for its units: the value's offsets, hence its length; the words of the arena that
+//      hold the value are requested at once and stay in registers until phase 3
+//   2  one lane per row: prefix of the field lengths -> where each field starts in the row, and
+//      the row's start in the text (closed form, or the measured starts in exact mode)
+//   3  every lane, for its units: the piece into the staging window in LDS
+//   4  the window to HBM in 16-byte stores
+// Rows whose text passes the window repeat 3-4 per window, byte by byte; units beyond UPL per lane
+// and values longer than the words fetched ahead read the arena in phase 3.
 template <bool EXACT>
 __global__ __launch_bounds__(FMT_BLOCK) void format_kernel(const FormatParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x;
-    const uint32_t R = P.R, ncols = P.ncols;
-    const uint64_t r0 = (uint64_t)blockIdx.x << P.Rshift;
+    const uint32_t R = P.R, ncols = P.ncols, Rshift = P.Rshift;
+    const uint64_t r0 = (uint64_t)blockIdx.x << Rshift;
     const uint32_t nrec = (uint32_t)(P.rows - r0 < R ? P.rows - r0 : R);
 
     const FormatField *fld = (const FormatField *)lds;
     const uint32_t *const *offp = (const uint32_t *const *)(lds + P.lds_ptrs);
     const uint8_t *const *bytp = (const uint8_t *const *)(lds + P.lds_ptrs + 8 * ncols);
     uint32_t *cpos = (uint32_t *)(lds + P.lds_cpos);
+    uint32_t *srcs = (uint32_t *)(lds + P.lds_src);
     uint64_t *rstart = (uint64_t *)(lds + P.lds_rstart);
     uint8_t *rflag = lds + P.lds_rflag;
     uint64_t *misc = (uint64_t *)(lds + P.lds_misc); // [0] block start, [1] block end, [2] bad
@@ -75,30 +100,105 @@ __global__ __launch_bounds__(FMT_BLOCK) void format_kernel(const FormatParams P)
     if (lane == 0) misc[2] = 0;
     __syncthreads();
 
-    // one lane per row: where its fields start, where the row starts
-    if (lane < nrec) {
-        const uint64_t r = r0 + lane;
-        uint64_t sum = 0;
-        uint32_t run = 0, bad = 0, cut = 0;
-#pragma unroll 4
-        for (uint32_t c = 0; c < ncols; ++c) {
-            fg_u32 *o = (fg_u32 *)offp[c];
-            uint32_t a = o[r], b = o[r + 1];
-            uint32_t len = b - a;
-            if (b < a) {
+    // ---- phase 1
+    const uint32_t cells = ncols << Rshift;
+    uint32_t ua[UPL], ub[UPL], ulen[UPL], uw[UPL][PW];
+    uint32_t bad = 0, cut = 0;
+    // units beyond the ones kept in registers: lengths only
+    for (uint32_t u = lane + UPL * FMT_BLOCK; u < cells; u += FMT_BLOCK) {
+        const uint32_t i = u & (R - 1), c = u >> Rshift;
+        if (i >= nrec) continue;
+        fg_u32 *o = (fg_u32 *)offp[c];
+        const uint32_t a = o[r0 + i], b = o[r0 + i + 1];
+        uint32_t len = b - a;
+        if (b < a) {
+            bad = 1;
+            len = 0;
+        }
+        if (EXACT)
+            len = ((fg_u32 *)P.elen)[(uint64_t)c * P.rows + r0 + i];
+        else if (fld[c].fieldlen && len > fld[c].fieldlen)
+            cut = 1;
+        cpos[u] = len;
+        srcs[u] = a;
+    }
+    // (a lane without a k-th unit reads unit 0's offsets instead: loads without a branch around
+    // them are all requested before the first wait)
+#pragma unroll
+    for (int k = 0; k < UPL; ++k) {
+        const uint32_t u = lane + k * FMT_BLOCK;
+        const uint32_t us = u < cells && (u & (R - 1)) < nrec ? u : 0;
+        const uint32_t i = us & (R - 1), c = us >> Rshift;
+        fg_u32 *o = (fg_u32 *)offp[c];
+        ua[k] = o[r0 + i];
+        ub[k] = o[r0 + i + 1];
+        ulen[k] = EXACT ? ((fg_u32 *)P.elen)[(uint64_t)c * P.rows + r0 + i] : 0;
+    }
+    // Every lane waits for its offsets here, branch or not: registers with a load that some path
+    // never waited for would otherwise make the compiler wait for the value words too at the
+    // next reuse of those registers, long before phase 3.
+#pragma unroll
+    for (int k = 0; k < UPL; ++k) asm volatile("" : "+v"(ua[k]), "+v"(ub[k]), "+v"(ulen[k]));
+    // lengths first, then the requests for the value words
+    fg_u32 *uptr[UPL];
+    uint32_t unw[UPL];
+#pragma unroll
+    for (int k = 0; k < UPL; ++k) {
+        const uint32_t u = lane + k * FMT_BLOCK, i = u & (R - 1), c = u >> Rshift;
+        unw[k] = 0;
+        uptr[k] = nullptr;
+        if (u < cells && i < nrec) {
+            uint32_t len = ub[k] - ua[k];
+            if (ub[k] < ua[k]) {
                 bad = 1;
                 len = 0;
             }
-            const uint32_t fl = fld[c].fieldlen;
             if (EXACT)
-                len = ((fg_u32 *)P.elen)[(uint64_t)c * P.rows + r];
-            else if (fl && len > fl)
+                len = ulen[k];
+            else if (fld[c].fieldlen && len > fld[c].fieldlen)
                 cut = 1;
-            cpos[c * R + lane] = run;
-            run += 2 * fld[c].name_len + 5 + len;
-            sum += a;
+            ulen[k] = len;
+            cpos[u] = len;
+            srcs[u] = ua[k];
+            const uint64_t ga = (uint64_t)(bytp[c] + ua[k]);
+            const uint32_t sh = (uint32_t)ga & 3;
+            uptr[k] = (fg_u32 *)(ga - sh);
+            unw[k] = len ? (sh + len + 3) >> 2 : 0;
         }
-        cpos[ncols * R + lane] = run;
+    }
+#pragma unroll
+    for (int k = 0; k < UPL; ++k) {
+#pragma unroll
+        for (int j = 0; j < PW; ++j) uw[k][j] = (uint32_t)j < unw[k] && !FSKIP(1) ? uptr[k][j] : 0;
+    }
+    if (bad) misc[2] = 1;
+    if (cut) atomicOr(P.status, FS_NEED_EXACT);
+    __syncthreads();
+
+    // ---- phase 2
+    if (lane < nrec) {
+        const uint64_t r = r0 + lane;
+        uint64_t sum = 0;
+        uint32_t run = 0;
+        for (uint32_t c0 = 0; c0 < ncols; c0 += 4) { // reads of four columns, then their writes
+            uint32_t len[4], nl[4], sr[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = c0 + q < ncols;
+                const uint32_t c = in ? c0 + q : c0;
+                len[q] = cpos[(c << Rshift) + lane];
+                sr[q] = in ? srcs[(c << Rshift) + lane] : 0;
+                nl[q] = fld[c].name_len;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c0 + q < ncols) {
+                    cpos[((c0 + q) << Rshift) + lane] = run;
+                    run += 2 * nl[q] + 5 + len[q];
+                    sum += sr[q];
+                }
+        }
+        cpos[cells + lane] = run;
         const uint64_t body = EXACT ? P.recpos[r] : r * P.fixed + sum - P.sumbase;
         const FilePos fp = file_pos(r, P.maxcount, P.rows);
         const uint64_t start = body + fp.framing;
@@ -107,9 +207,7 @@ __global__ __launch_bounds__(FMT_BLOCK) void format_kernel(const FormatParams P)
         rflag[lane] = (op ? 1 : 0) | (cl ? 2 : 0);
         if (lane == 0) misc[0] = start;
         if (lane == nrec - 1) misc[1] = start + (op ? 7 : 0) + run + 8 + (cl ? 8 : 0);
-        if (bad) misc[2] = 1;
-        if (cut) atomicOr(P.status, FS_NEED_EXACT);
-        if (op && !bad) P.file_off[fp.file] = start;
+        if (op && !misc[2]) P.file_off[fp.file] = start;
     }
     __syncthreads();
     if (misc[2]) {
@@ -120,63 +218,202 @@ __global__ __launch_bounds__(FMT_BLOCK) void format_kernel(const FormatParams P)
     const uint64_t blk_hi = misc[1] < P.total ? misc[1] : P.total;
     if (blk_lo >= blk_hi) return;
 
-    const uint8_t *consts = lds + P.const_off; // "<endl/>\n</data>\n<data>\n"
-    const uint32_t units = (ncols + 1) << P.Rshift;
     uint32_t sawcut = 0;
-
-    for (uint64_t wlo = blk_lo & ~15ull; wlo < blk_hi; wlo += STAGE) {
+    auto nul_in = [&](uint32_t v, uint32_t m) { // a NUL among the low m bytes of v
+        uint32_t z = (v - 0x01010101u) & ~v & 0x80808080u;
+        if (m < 4) z &= (1u << (8 * m)) - 1;
+        sawcut |= z;
+    };
+    // the window [wlo, wlo + STAGE) to HBM: whole 16-byte groups, bytes at the block's two ends
+    auto copy_out = [&](uint64_t wlo) {
         const uint64_t whi = wlo + STAGE;
-        // bytes [k0, k1) of a piece of n bytes at text position p that fall into this window
-        auto clip = [&](uint64_t p, uint32_t n, uint32_t &k0, uint32_t &k1) {
-            k0 = p >= wlo ? 0 : (wlo - p < n ? (uint32_t)(wlo - p) : n);
-            k1 = p + n <= whi ? n : (p >= whi ? 0 : (uint32_t)(whi - p));
-        };
-        auto put_lds = [&](uint64_t p, const uint8_t *src, uint32_t n) {
-            uint32_t k0, k1;
-            clip(p, n, k0, k1);
-            const uint32_t s = (uint32_t)(p - wlo); // exact modulo 2^32 for the bytes in range
-            for (uint32_t k = k0; k < k1; ++k) stage[s + k] = src[k];
-        };
-
-        for (uint32_t u = lane; u < units; u += FMT_BLOCK) {
-            const uint32_t i = u & (R - 1), c = u >> P.Rshift;
-            if (i >= nrec) continue;
-            const uint64_t dst = rstart[i] + cpos[c * R + i];
-            if (c == ncols) {
-                const uint32_t fl = rflag[i];
-                put_lds(dst, consts, (fl & 2) ? 16 : 8);
-                if (fl & 1) put_lds(rstart[i] - 7, consts + 16, 7);
-                continue;
+        const uint64_t lo = wlo > blk_lo ? wlo : blk_lo;
+        const uint64_t hi = whi < blk_hi ? whi : blk_hi;
+        for (uint32_t j = lane; j * 16 < STAGE; j += FMT_BLOCK) {
+            const uint64_t g = wlo + 16ull * j;
+            if (g >= hi) break;
+            if (FSKIP(2)) continue;
+            if (g >= lo && g + 16 <= hi) {
+                *(fu32x4 *)(P.out + g) = *(const fu32x4 *)(stage + 16 * j);
+            } else {
+                for (uint32_t b = 0; b < 16; ++b)
+                    if (g + b >= lo && g + b < hi) P.out[g + b] = stage[16 * j + b];
             }
-            const uint32_t nl = fld[c].name_len;
-            const uint32_t len = cpos[(c + 1) * R + i] - cpos[c * R + i] - (2 * nl + 5);
-            if (dst + 2 * nl + 5 + len <= wlo || dst >= whi) continue;
-            const uint8_t *tag = lds + fld[c].text_off;
-            put_lds(dst, tag, nl + 2);
-            put_lds(dst + nl + 2 + len, tag + nl + 2, nl + 3);
+        }
+    };
+    // the pieces of unit u: position and length of the leading text (first field only), the value
+    // and the text after it
+    struct Piece {
+        uint64_t vpos;
+        uint32_t len, c, pre_off, pre_n, join_off, join_n;
+    };
+    auto piece_of = [&](uint32_t u) {
+        Piece q;
+        const uint32_t i = u & (R - 1);
+        q.c = u >> Rshift;
+        const uint32_t nl = fld[q.c].name_len, fl = rflag[i];
+        q.len = cpos[u + R] - cpos[u] - (2 * nl + 5);
+        q.vpos = rstart[i] + cpos[u] + nl + 2;
+        q.pre_n = q.c ? 0 : nl + 2 + ((fl & 1) ? 7 : 0);
+        q.pre_off = (fl & 1) ? P.pre_open_off : P.pre_plain_off;
+        q.join_off = fld[q.c].text_off;
+        q.join_n = fld[q.c].join_len + ((fl & 2) && q.c + 1 == ncols ? 8 : 0);
+        return q;
+    };
 
-            // the value: aligned words of the arena, shifted into place
-            uint32_t k0, k1;
-            const uint64_t vp = dst + nl + 2;
-            clip(vp, len, k0, k1);
-            if (k0 < k1) {
-                const uint32_t a = ((fg_u32 *)offp[c])[r0 + i];
-                const uint64_t ga = (uint64_t)(bytp[c] + a + k0);
+    const uint64_t w0 = blk_lo & ~15ull;
+    if (blk_hi - w0 <= STAGE) {
+        // ---- phases 3 and 4, the whole block in one window.  A piece is streamed into aligned
+        // words of the window: bytes wait in `acc` until four are there; only the piece's first
+        // and last word, shared with the neighbouring pieces, are written byte by byte.
+        struct Stream {
+            uint64_t acc; // pending bytes, low ones first
+            uint32_t f;   // how many (0..3 between pushes)
+            uint32_t dp;  // window offset of the next word
+            bool head;    // the next word is the piece's first and starts before the piece
+            uint32_t al;  // bytes of the first word that belong to the piece before
+        };
+        auto emit = [&](Stream &st) {
+            const uint32_t x = (uint32_t)st.acc;
+            if (st.head) {
+                if (st.al <= 1) stage[st.dp + 1] = (uint8_t)(x >> 8);
+                if (st.al <= 2) stage[st.dp + 2] = (uint8_t)(x >> 16);
+                stage[st.dp + 3] = (uint8_t)(x >> 24);
+                st.head = false;
+            } else {
+                *(uint32_t *)(stage + st.dp) = x;
+            }
+            st.acc >>= 32;
+            st.dp += 4;
+        };
+        auto push4 = [&](Stream &st, uint32_t w) {
+            st.acc |= (uint64_t)w << (8 * st.f);
+            emit(st);
+        };
+        auto push = [&](Stream &st, uint32_t w, uint32_t n) { // the low n bytes of w, the rest zero
+            st.acc |= (uint64_t)w << (8 * st.f);
+            st.f += n;
+            if (st.f >= 4) {
+                emit(st);
+                st.f -= 4;
+            }
+        };
+        // text of the blob: 16-aligned, zero padded to the next multiple of 16
+        auto push_text = [&](Stream &st, uint32_t off, uint32_t n) {
+            for (uint32_t k = 0; k < n; k += 16) {
+                const fu32x4 t = *(const fu32x4 *)(lds + off + k);
+                const uint32_t m = n - k;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (m >= 4u * j + 4)
+                        push4(st, t[j]);
+                    else if (m > 4u * j)
+                        push(st, t[j], m - 4 * j);
+                }
+            }
+        };
+        auto unit = [&](uint32_t u, const uint32_t *pre, uint32_t klen, uint32_t ka) {
+            const uint32_t i = u & (R - 1), c = u >> Rshift;
+            const fu32x4 F = *(const fu32x4 *)(lds + 16 * c); // text_off, name_len, fieldlen, join_len
+            const uint32_t nl = F[1], fl = rflag[i];
+            const uint32_t len = pre ? klen : cpos[u + R] - cpos[u] - (2 * nl + 5);
+            const uint32_t a = pre ? ka : srcs[u];
+            const uint32_t s = (uint32_t)(rstart[i] - w0) + cpos[u]; // where "<name>" starts
+            const uint32_t ps = c ? s + nl + 2 : s - ((fl & 1) ? 7 : 0);
+            Stream st;
+            st.acc = 0;
+            st.al = st.f = ps & 3;
+            st.dp = ps & ~3u;
+            st.head = st.al != 0;
+            if (c == 0) push_text(st, (fl & 1) ? P.pre_open_off : P.pre_plain_off, nl + 2 + ((fl & 1) ? 7 : 0));
+            const uint64_t gbase = (uint64_t)(bytp[c] + a);
+            const uint32_t sh = (uint32_t)gbase & 3;
+            if (pre && sh + len <= 4 * PW) {
+#pragma unroll
+                for (int j = 0; j < PW; ++j)
+                    if ((uint32_t)j * 4 < len) {
+                        uint32_t v = __builtin_amdgcn_alignbyte(j + 1 < PW ? pre[j + 1] : 0, pre[j], sh);
+                        const uint32_t m = len - 4 * j;
+                        if (m >= 4) {
+                            if (!EXACT) nul_in(v, 4);
+                            push4(st, v);
+                        } else {
+                            v &= (1u << (8 * m)) - 1;
+                            if (!EXACT) nul_in(v | (0x01010101u << (8 * m)), 4);
+                            push(st, v, m);
+                        }
+                    }
+            } else if (len) {
+                fg_u32 *w = (fg_u32 *)(gbase - sh);
+                const uint32_t nwords = (sh + len + 3) >> 2;
+                uint32_t lo = w[0];
+                for (uint32_t j = 0; j * 4 < len; ++j) {
+                    const uint32_t hi = j + 1 < nwords ? w[j + 1] : 0;
+                    uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                    const uint32_t m = len - 4 * j;
+                    if (m >= 4) {
+                        if (!EXACT) nul_in(v, 4);
+                        push4(st, v);
+                    } else {
+                        v &= (1u << (8 * m)) - 1;
+                        if (!EXACT) nul_in(v | (0x01010101u << (8 * m)), 4);
+                        push(st, v, m);
+                    }
+                    lo = hi;
+                }
+            }
+            push_text(st, F[0], F[3] + ((fl & 2) && c + 1 == ncols ? 8 : 0));
+            // what is left belongs to the piece's last word
+            const uint32_t x = (uint32_t)st.acc;
+            if (st.f > 0) stage[st.dp] = (uint8_t)x;
+            if (st.f > 1) stage[st.dp + 1] = (uint8_t)(x >> 8);
+            if (st.f > 2) stage[st.dp + 2] = (uint8_t)(x >> 16);
+        };
+#pragma unroll
+        for (int k = 0; k < UPL; ++k) {
+            const uint32_t u = lane + k * FMT_BLOCK;
+            if (u < cells && (u & (R - 1)) < nrec && !FSKIP(4)) unit(u, uw[k], ulen[k], ua[k]);
+        }
+        for (uint32_t u = lane + UPL * FMT_BLOCK; u < cells; u += FMT_BLOCK)
+            if ((u & (R - 1)) < nrec) unit(u, nullptr, 0, 0);
+        __syncthreads();
+        copy_out(w0);
+    } else {
+        // ---- phases 3 and 4 window by window: every piece clipped to the window, byte by byte
+        for (uint64_t wlo = w0; wlo < blk_hi; wlo += STAGE) {
+            const uint64_t whi = wlo + STAGE;
+            // bytes [k0, k1) of n bytes at text position p that fall into this window
+            auto clip = [&](uint64_t p, uint32_t n, uint32_t &k0, uint32_t &k1) {
+                k0 = p >= wlo ? 0 : (wlo - p < n ? (uint32_t)(wlo - p) : n);
+                k1 = p + n <= whi ? n : (p >= whi ? 0 : (uint32_t)(whi - p));
+            };
+            auto put_lds = [&](uint64_t p, const uint8_t *src, uint32_t n) {
+                uint32_t k0, k1;
+                clip(p, n, k0, k1);
+                const uint32_t s = (uint32_t)(p - wlo); // exact modulo 2^32 for the bytes in range
+                for (uint32_t k = k0; k < k1; ++k) stage[s + k] = src[k];
+            };
+            for (uint32_t u = lane; u < cells; u += FMT_BLOCK) {
+                if ((u & (R - 1)) >= nrec) continue;
+                const Piece q = piece_of(u);
+                if (q.vpos + q.len + q.join_n <= wlo || q.vpos - q.pre_n >= whi) continue;
+                if (q.pre_n) put_lds(q.vpos - q.pre_n, lds + q.pre_off, q.pre_n);
+                put_lds(q.vpos + q.len, lds + q.join_off, q.join_n);
+                uint32_t k0, k1;
+                clip(q.vpos, q.len, k0, k1);
+                if (k0 >= k1) continue;
+                const uint64_t ga = (uint64_t)(bytp[q.c] + srcs[u]) + k0;
                 const uint32_t sh = (uint32_t)ga & 3;
                 fg_u32 *w = (fg_u32 *)(ga - sh);
                 const uint32_t n = k1 - k0;
                 const uint32_t nwords = (sh + n + 3) >> 2;
-                uint32_t s = (uint32_t)(vp - wlo) + k0;
+                uint32_t s = (uint32_t)(q.vpos - wlo) + k0;
                 uint32_t lo = w[0];
                 for (uint32_t j = 0; j * 4 < n; ++j) {
                     const uint32_t hi = j + 1 < nwords ? w[j + 1] : 0;
                     const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, sh);
                     const uint32_t m = n - j * 4 < 4 ? n - j * 4 : 4;
-                    if (!EXACT) {
-                        uint32_t z = (v - 0x01010101u) & ~v & 0x80808080u;
-                        if (m < 4) z &= (1u << (8 * m)) - 1;
-                        sawcut |= z;
-                    }
+                    if (!EXACT) nul_in(v, m);
                     stage[s] = (uint8_t)v;
                     if (m > 1) stage[s + 1] = (uint8_t)(v >> 8);
                     if (m > 2) stage[s + 2] = (uint8_t)(v >> 16);
@@ -185,22 +422,10 @@ __global__ __launch_bounds__(FMT_BLOCK) void format_kernel(const FormatParams P)
                     lo = hi;
                 }
             }
+            __syncthreads();
+            copy_out(wlo);
+            __syncthreads();
         }
-        __syncthreads();
-
-        const uint64_t lo = wlo > blk_lo ? wlo : blk_lo;
-        const uint64_t hi = whi < blk_hi ? whi : blk_hi;
-        for (uint32_t j = lane; j * 16 < STAGE; j += FMT_BLOCK) {
-            const uint64_t g = wlo + 16ull * j;
-            if (g >= hi) break;
-            if (g >= lo && g + 16 <= hi) {
-                *(fu32x4 *)(P.out + g) = *(const fu32x4 *)(stage + 16 * j);
-            } else {
-                for (uint32_t b = 0; b < 16; ++b)
-                    if (g + b >= lo && g + b < hi) P.out[g + b] = stage[16 * j + b];
-            }
-        }
-        __syncthreads();
     }
     if (!EXACT && sawcut) atomicOr(P.status, FS_NEED_EXACT);
 }

@@ -3,6 +3,7 @@
     python tools/format_bench.py [bytes] [maxcount] [lds budget]
 """
 import ctypes
+import os
 import sys
 
 import numpy as np
@@ -12,6 +13,8 @@ from dsp_amd import capi, gen, schema  # noqa: E402
 
 
 def main():
+    if os.environ.get("MDC_FORMAT_SKIP"):
+        capi.LIB_PATH = os.path.join("dsp_amd", "libmdc_parse_ablate.so")
     nbytes = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 30
     maxcount = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     cols = schema.ZHOBTMIND
@@ -24,11 +27,18 @@ def main():
     b = p.parse_device(buf.ptr, buf.n)
     best = None
     for it in range(8):
-        t = f.format_batch(b, maxcount)
+        try:
+            t = f.format_batch(b, maxcount)
+        except capi.MdcError:
+            if not os.environ.get("MDC_FORMAT_SKIP"):
+                raise
+            t = None  # (an ablated run may see NULs in what it did not write)
+
         tm = f.timing()
         if best is None or tm.format_ms < best[0]:
             best = (tm.format_ms, tm.total_ms, tm.bytes_in, tm.bytes_out)
-        t.free()
+        if t is not None:
+            t.free()
     ms, tot, bi, bo = best
     print(f"rows {rows} text {bo / 2**30:.3f} GiB in {ms:.3f} ms (call {tot:.3f} ms): "
           f"{bo / ms / 1e6:.1f} GB/s of text, {(bi + bo) / ms / 1e6:.1f} GB/s read+written", flush=True)
