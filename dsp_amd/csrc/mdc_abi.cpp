@@ -1059,7 +1059,7 @@ struct mdc_formatter {
     std::vector<uint8_t> blob;
     uint32_t pre_plain_off = 0, pre_open_off = 0;
     uint32_t fixed = 0;          // bytes per record that are not values
-    uint32_t lds_budget = 20 * 1024;
+    uint32_t lds_budget = 22 * 1024 + 512; // seven blocks of the formatting kernel per compute unit
     void *d_blob = nullptr;
     void *d_tab = nullptr;       // ncols off pointers, ncols byte pointers, ncols arena sizes
     void *h_tab = nullptr;       // pinned image of d_tab
