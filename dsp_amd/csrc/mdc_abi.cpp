@@ -649,6 +649,9 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     P.n = n;
     P.schema = (const uint8_t *)p->d_blob;
     P.schema_bytes = (uint32_t)p->blob.size();
+    P.ncols = (uint32_t)p->ncols;
+    P.words = p->words;
+    P.p10_off = ((const SchemaHdr *)p->blob.data())->p10_off;
     P.ntiles = (uint32_t)ntiles;
     P.tile_counts = p->d_counts;
     P.tile_base = p->d_base;

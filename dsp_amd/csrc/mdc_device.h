@@ -110,6 +110,7 @@ struct TileParams {
     uint64_t n;
     const uint8_t *schema;
     uint32_t schema_bytes;
+    uint32_t ncols, words, p10_off;  // copies of the schema header's fields (kernel arguments need no load)
     uint32_t ntiles;
     LdsLayout L;
     // count mode output / write mode input

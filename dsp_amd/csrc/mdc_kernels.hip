@@ -814,24 +814,42 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         return make_uint4(w[0], w[1], w[2], w[3]);
     };
 
-    // ---- A. coalesced 16-byte loads of the tile, the first look-behind window and the schema
-    {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = ts_li / CHUNK + k * BLOCK + tid;
-            ((uint4 *)sdata)[j] = j * CHUNK < te_li ? load_chunk(j) : make_uint4(0, 0, 0, 0);
-        }
-    }
-    int loaded_lo = ts_li;
+    // ---- A. coalesced 16-byte loads of the tile, the first look-behind window and the schema.
+    // Every load is requested before the first one is waited for; for that no load may stand
+    // behind a branch (the compiler waits at the end of a branch for what was loaded in it), so
+    // a tile that lies whole in the input takes plain loads, and a lane without a look-behind or
+    // schema chunk of its own loads one it then drops.
+    int loaded_lo = ts_li, jlb = 0;
+    bool lbmine = false;
     if (tile_start > 0) {
         loaded_lo = ts_li - LB_FIRST < li_min ? li_min : ts_li - LB_FIRST;
-        const int j = loaded_lo / CHUNK + tid;
-        if (j < ts_li / CHUNK) ((uint4 *)sdata)[j] = load_chunk(j);
+        jlb = loaded_lo / CHUNK + tid;
+        lbmine = jlb < ts_li / CHUNK;
     }
     {
         const uint4 *g = (const uint4 *)P.schema;
         uint4 *s = (uint4 *)(smem + L.schema);
-        for (uint32_t i = tid; i < P.schema_bytes / 16; i += BLOCK) s[i] = g[i];
+        const uint32_t sch16 = P.schema_bytes / 16;
+        uint4 tv[4], lbv;
+        if (tile_start + TILE <= n) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                tv[k] = *(const uint4 *)(P.data + (base_pos + (int64_t)(ts_li / CHUNK + k * BLOCK + tid) * CHUNK));
+            lbv = *(const uint4 *)(P.data + (base_pos + (int64_t)(lbmine ? jlb : ts_li / CHUNK) * CHUNK));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = ts_li / CHUNK + k * BLOCK + tid;
+                tv[k] = j * CHUNK < te_li ? load_chunk(j) : make_uint4(0, 0, 0, 0);
+            }
+            lbv = lbmine ? load_chunk(jlb) : make_uint4(0, 0, 0, 0);
+        }
+        const uint4 sv = g[(uint32_t)tid < sch16 ? tid : 0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ((uint4 *)sdata)[ts_li / CHUNK + k * BLOCK + tid] = tv[k];
+        if (lbmine) ((uint4 *)sdata)[jlb] = lbv;
+        if ((uint32_t)tid < sch16) s[tid] = sv;
+        for (uint32_t i = tid + BLOCK; i < sch16; i += BLOCK) s[i] = g[i];
         if (tid < MS_COUNT) ms[tid] = tid == MS_LAST ? NONE : 0;
     }
     __syncthreads();
@@ -1323,8 +1341,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: scalar loads for per-column data)
     const uint32_t tile = blockIdx.x;
-    const SchemaHdr *Hg = (const SchemaHdr *)P.schema;
-    const uint32_t ncols = Hg->ncols, W = Hg->words;
+    const uint32_t ncols = P.ncols, W = P.words;
     if (tile == 0) {
         if (tid == 0 && P.rec_off) P.rec_off[0] = 0;
         for (uint32_t c = tid; c < ncols; c += BLOCK) P.off[c][0] = 0;
@@ -1332,10 +1349,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     // Everything the block needs is requested before anything is waited for: the tile's header
     // words, the tile itself, the first look-behind window and the tile's slice of the cell map
     // (whose place, tile * map_stride, does not depend on the header).
-    const uint32_t hslot = P.tile_hdr[2 * tile];
-    const uint32_t hw = P.tile_hdr[2 * tile + 1];
-    const uint32_t nrec = P.tile_counts[(uint64_t)tile * (ncols + 1) + ncols];
     const uint32_t slot = tile * P.map_stride;
+    // The tile's header words are the same for every lane, and the compiler would fetch them into
+    // scalar registers at once, which is a wait in front of all the other loads: a zero it
+    // cannot see through keeps them per-lane values until they are needed.
+    uint32_t vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    const uint32_t hslot_v = P.tile_hdr[2 * tile + vz];
+    const uint32_t hw_v = P.tile_hdr[2 * tile + 1 + vz];
+    const uint32_t nrec_v = P.tile_counts[(uint64_t)tile * (ncols + 1) + ncols + vz];
+    const uint64_t row0_v = P.tile_base[(uint64_t)tile * (ncols + 1) + ncols + vz];
 
     const int64_t n = (int64_t)P.n;
     const int64_t tile_start = (int64_t)tile * TILE;
@@ -1353,16 +1376,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             if (pos + k < n) w[k >> 2] |= (uint32_t)P.data[pos + k] << (8 * (k & 3));
         return make_uint4(w[0], w[1], w[2], w[3]);
     };
+    // (no load may stand behind a branch: the compiler waits at the end of a branch for what was
+    // loaded in it.  A tile that lies whole in the input takes plain loads; a lane without a chunk,
+    // map word or table entry of its own loads one that it then drops)
     uint4 tv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int j = ts_li / CHUNK + k * BLOCK + tid;
-        tv[k] = j * CHUNK < te_li ? load_chunk(j) : make_uint4(0, 0, 0, 0);
-    }
     const int jw = (ts_li - LB_FIRST) / CHUNK + tid;  // this thread's chunk of the first look-behind window
     const bool lbmine = tid < LB_FIRST / CHUNK && base_pos + (int64_t)jw * CHUNK >= 0;
-    uint4 lbv = make_uint4(0, 0, 0, 0);
-    if (lbmine) lbv = load_chunk(jw);
+    uint4 lbv;
+    if (tile_start + TILE <= n) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            tv[k] = *(const uint4 *)(P.data + (base_pos + (int64_t)(ts_li / CHUNK + k * BLOCK + tid) * CHUNK));
+        lbv = *(const uint4 *)(P.data + (base_pos + (int64_t)(lbmine ? jw : ts_li / CHUNK) * CHUNK));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = ts_li / CHUNK + k * BLOCK + tid;
+            tv[k] = j * CHUNK < te_li ? load_chunk(j) : make_uint4(0, 0, 0, 0);
+        }
+        lbv = lbmine ? load_chunk(jw) : make_uint4(0, 0, 0, 0);
+    }
     const uint32_t RB = L.RB;
     const uint32_t RBs = P.map_stride < RB ? P.map_stride : RB;  // records of the first batch, at most
     const uint32_t nwords = (ncols + 1) * RBs;
@@ -1371,33 +1404,45 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     uint32_t mv[MAPREG];
 #pragma unroll
     for (int k = 0; k < MAPREG; ++k) {
-        const uint32_t i = (uint32_t)k * BLOCK + tid;
+        const uint32_t i0 = (uint32_t)k * BLOCK + tid;
+        const uint32_t i = i0 < nwords ? i0 : 0;
         const uint32_t c = RBs == 1 ? i : __umulhi(i, magic_s);
-        mv[k] = i < nwords ? P.cellmap[(uint64_t)c * P.map_cap + slot + (i - c * RBs)] : 0u;
+        mv[k] = P.cellmap[(uint64_t)c * P.map_cap + slot + (i - c * RBs)];
     }
     // of the schema only the header, the columns and the powers of ten (the tag table stays out)
     const uint32_t sch_head = (uint32_t)sizeof(SchemaHdr) + ((ncols * (uint32_t)sizeof(DevCol) + 15) & ~15u);
-    {
-        const uint4 *g = (const uint4 *)P.schema;
-        uint4 *s = (uint4 *)(smem + L.schema);
-        for (uint32_t i = tid; i < sch_head / 16; i += BLOCK) s[i] = g[i];
-        const uint64_t *gp = (const uint64_t *)(P.schema + Hg->p10_off);
-        uint64_t *sp = (uint64_t *)(smem + L.schema + sch_head);
-        if (tid < 23) sp[tid] = gp[tid];
-    }
     uint32_t *tiletot = (uint32_t *)(smem + L.coltot);
     ColOut *colout = (ColOut *)(smem + L.colout);
     const uint64_t *tb = P.tile_base + (uint64_t)tile * (ncols + 1);
-    for (uint32_t c = tid; c < ncols; c += BLOCK) {
-        tiletot[c] = 0;
+    {
+        // (a thread beyond a table's end copies entry 0 once more: the same bytes to the same
+        // place, and no branch around the load)
+        const uint4 *g = (const uint4 *)P.schema;
+        uint4 *s = (uint4 *)(smem + L.schema);
+        const uint64_t *gp = (const uint64_t *)(P.schema + P.p10_off);
+        uint64_t *sp = (uint64_t *)(smem + L.schema + sch_head);
+        const uint32_t sch16 = sch_head / 16;
+        const uint32_t si = (uint32_t)tid < sch16 ? tid : 0;
+        const uint32_t pi = tid < 23 ? tid : 0;
+        const uint32_t cc = (uint32_t)tid < ncols ? tid : 0;
+        const uint4 sv = g[si];
+        const uint64_t pv = gp[pi];
         ColOut o;
-        o.off = P.off[c];
-        o.bytes = P.bytes[c];
-        o.val = P.val[c];
-        o.base = tb[c];
-        colout[c] = o;
+        o.off = P.off[cc];
+        o.bytes = P.bytes[cc];
+        o.val = P.val[cc];
+        o.base = tb[cc];
+        s[si] = sv;
+        for (uint32_t i = tid + BLOCK; i < sch16; i += BLOCK) s[i] = g[i];
+        sp[pi] = pv;
+        tiletot[cc] = 0;
+        colout[cc] = o;
     }
-    const uint64_t row0 = tb[ncols];
+    const uint32_t hslot = __builtin_amdgcn_readfirstlane(hslot_v);
+    const uint32_t hw = __builtin_amdgcn_readfirstlane(hw_v);
+    const uint32_t nrec = __builtin_amdgcn_readfirstlane(nrec_v);
+    const uint64_t row0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(row0_v >> 32)) << 32) |
+                          __builtin_amdgcn_readfirstlane((uint32_t)row0_v);
 
     if (hslot == NONE || nrec == 0) return;  // no map (the full write kernel has the tile), or nothing to write
     const int s0_li = (int)(hw & 0x7FFFFFFFu);
