@@ -39,9 +39,9 @@ def _run(cmd):
 
 def build_parse(force=False):
     target = os.path.join(HERE, "libmdc_parse.so")
-    srcs = [os.path.join(CSRC, f) for f in ("mdc_kernels.hip", "mdc_format.hip", "mdc_abi.cpp", "mdc_stream.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("mdc_kernels.hip", "mdc_format.hip", "mdc_abi.cpp", "mdc_stream.cpp", "mdc_route.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("mdc_device.h", "mdc_numparse.h", "mdc_bignum.h")] + \
-        [os.path.join(ROOT, "include", f) for f in ("mdc_parse.h", "mdc_format.h")]
+        [os.path.join(ROOT, "include", f) for f in ("mdc_parse.h", "mdc_format.h", "mdc_route.h")]
     if force or _newer(target, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         _run([hipcc] + HIPCC_FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-x", "hip"] + srcs +
@@ -53,7 +53,7 @@ def build_diag(force=True, define="MDC_PHASE_TIMING", name="libmdc_parse_diag.so
     """Diagnostic variants (never used by tests or bench): MDC_PHASE_TIMING adds per-phase cycle
     counters, MDC_ABLATE lets MDC_DEBUG_SKIP switch phases off."""
     target = os.path.join(HERE, name)
-    srcs = [os.path.join(CSRC, f) for f in ("mdc_kernels.hip", "mdc_format.hip", "mdc_abi.cpp", "mdc_stream.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("mdc_kernels.hip", "mdc_format.hip", "mdc_abi.cpp", "mdc_stream.cpp", "mdc_route.cpp")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     _run([hipcc] + HIPCC_FLAGS + ["-D" + define, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
                                   "-x", "hip"] + srcs + ["-o", target, "-lz", "-pthread"])

@@ -51,10 +51,41 @@ static void print_columns(mdc_batch *b, int64_t row, int ncols, const std::vecto
 int main(int argc, char **argv) {
     if (argc < 4) {
         std::fprintf(stderr, "usage: %s xml <file> <name:type:collen[:typed],...> [nocarry]\n"
-                             "       %s csv <file> <sep> <nfields> [typed,...]\n", argv[0], argv[0]);
+                             "       %s csv <file> <sep> <nfields> [typed,...]\n"
+                             "       %s route <inifile> <xmlfile name> <name:type:collen:typed:pkseq,...>\n",
+                     argv[0], argv[0], argv[0]);
         return 2;
     }
     const std::string mode = argv[1], filename = argv[2];
+    if (mode == "route") {
+        // tools/xmltodb.cpp:141, :236-246: load the routing entries, find the file's entry, build the
+        // statements and the bind order for the table's columns
+        if (argc < 5) return 2;
+        std::vector<mdc::st_col> cols;
+        for (const std::string &spec : split(argv[4], ',')) {
+            const std::vector<std::string> f = split(spec, ':');
+            if (f.size() < 3) return 2;
+            cols.emplace_back(f[0], f[1], std::atoi(f[2].c_str()), f.size() > 3 ? std::atoi(f[3].c_str()) : MDC_T_NONE,
+                              f.size() > 4 ? std::atoi(f[4].c_str()) : 0);
+        }
+        mdc::cxmltotable tab;
+        if (!tab.loadxmltotable(filename)) {
+            std::fprintf(stderr, "loadxmltotable(%s) failed: %s\n", filename.c_str(), mdc_last_error());
+            return 5;
+        }
+        if (!tab.findxmltotable(argv[3])) return 1;  // "no routing entry"
+        std::vector<int> bi, bu;
+        if (!tab.crtsql(cols) || !tab.bindplan(cols, bi, bu)) return 2;
+        std::printf("tname %s\nuptbz %d\nexecsql %s\ninsert %s\n", tab.stxmltotable.tname, tab.stxmltotable.uptbz,
+                    tab.stxmltotable.execsql, tab.insertsql.c_str());
+        if (tab.stxmltotable.uptbz == 1) std::printf("update %s\n", tab.updatesql.c_str());
+        std::printf("bind_insert");
+        for (int c : bi) std::printf(" %d", c);
+        std::printf("\nbind_update");
+        for (int c : bu) std::printf(" %d", c);
+        std::printf("\n");
+        return 0;
+    }
     if (mode == "xml") {
         std::vector<mdc::st_col> cols;
         std::vector<int> typed;

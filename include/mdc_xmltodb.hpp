@@ -9,6 +9,8 @@
  *   splitbuffer(buf)             tools/xmltodb.cpp:492       cxmlfile::splitbuffer(v)  cells of the current record
  *   getxmlbuffer(xml,name,v)     public/_public.cpp:461-625  cxmlfile::getxmlbuffer(name,v) for the current record
  *   ccmdstr::splittocmd+getvalue public/_public.cpp:274-446  ccmdfile::getvalue(ii,v)  for the current line
+ *   loadxmltotable/findxmltotable tools/xmltodb.cpp:102,311  cxmltotable::loadxmltotable / findxmltotable
+ *   crtsql / preparesql          tools/xmltodb.cpp:325,421   cxmltotable::crtsql / bindplan
  *
  * Return conventions are the reference's: bool, true = found/converted, outputs untouched on
  * false, nothing throws.  errmsg() holds the library's text after a failed open().
@@ -23,6 +25,7 @@
 #include <vector>
 
 #include "mdc_parse.h"
+#include "mdc_route.h"
 
 namespace mdc {
 
@@ -386,6 +389,67 @@ class ccmdfile : public detail::bulkfile {
     const uint32_t *m_valid = nullptr, *m_found = nullptr;
     int m_words = 0;
     mutable std::vector<const uint64_t *> m_val;
+};
+
+/* The routing table of the ingest and the statements of the matched entry: the globals
+ * vxmltotable, stxmltotable, insertsql and updatesql of tools/xmltodb.cpp:35-56 as members. */
+class cxmltotable {
+   public:
+    cxmltotable() { std::memset(&stxmltotable, 0, sizeof(stxmltotable)); }
+    cxmltotable(const cxmltotable &) = delete;
+    cxmltotable &operator=(const cxmltotable &) = delete;
+    ~cxmltotable() {
+        if (m_route) mdc_route_free(m_route);
+    }
+
+    /* tools/xmltodb.cpp:102-129: false when the parameter file cannot be opened */
+    bool loadxmltotable(const std::string &inifilename) {
+        if (m_route) mdc_route_free(m_route);
+        m_route = nullptr;
+        return mdc_route_load(inifilename.c_str(), &m_route) == MDC_OK;
+    }
+    int size() const { return m_route ? mdc_route_count(m_route) : 0; }
+    const mdc_xmltotable *operator[](int i) const { return m_route ? mdc_route_entry(m_route, i) : nullptr; }
+
+    /* tools/xmltodb.cpp:311-323: the first entry whose rules match the file name is copied
+     * to stxmltotable; false (return code 1 of _xmltodb) when none matches */
+    bool findxmltotable(const std::string &xmlfile) {
+        const int i = m_route ? mdc_route_find(m_route, xmlfile.c_str()) : -1;
+        if (i < 0) return false;
+        stxmltotable = *mdc_route_entry(m_route, i);
+        return true;
+    }
+
+    /* tools/xmltodb.cpp:325-419 for stxmltotable and the given columns (tcols.m_vallcols);
+     * updatesql keeps its previous text when stxmltotable.uptbz != 1, as in the reference */
+    bool crtsql(const std::vector<st_col> &vallcols) {
+        std::vector<mdc_col> c(vallcols.begin(), vallcols.end());
+        size_t il = 0, ul = 0;
+        mdc_crtsql(&stxmltotable, c.data(), (int)c.size(), nullptr, 0, &il, nullptr, 0, &ul);  // sizes first
+        std::string ins(il + 1, '\0'), upd(ul + 1, '\0');
+        if (mdc_crtsql(&stxmltotable, c.data(), (int)c.size(), &ins[0], ins.size(), &il, &upd[0], upd.size(), &ul) != MDC_OK)
+            return false;
+        insertsql.assign(ins.data(), il);
+        if (stxmltotable.uptbz == 1) updatesql.assign(upd.data(), ul);
+        return true;
+    }
+    /* tools/xmltodb.cpp:421-477: columns bound to :1, :2, ... of the two statements */
+    bool bindplan(const std::vector<st_col> &vallcols, std::vector<int> &ins, std::vector<int> &upd) const {
+        std::vector<mdc_col> c(vallcols.begin(), vallcols.end());
+        ins.assign(c.size() + 1, 0);
+        upd.assign(c.size() + 1, 0);
+        int ni = 0, nu = 0;
+        if (mdc_bind_plan(&stxmltotable, c.data(), (int)c.size(), ins.data(), &ni, upd.data(), &nu) != MDC_OK) return false;
+        ins.resize((size_t)ni);
+        upd.resize((size_t)nu);
+        return true;
+    }
+
+    mdc_xmltotable stxmltotable;
+    std::string insertsql, updatesql;
+
+   private:
+    mdc_route *m_route = nullptr;
 };
 
 }  // namespace mdc

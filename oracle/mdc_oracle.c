@@ -535,4 +535,244 @@ int64_t ORC_FN(format_xml_files)(const char *const *fieldname, const int *fieldl
     return done == nfiles ? nfiles : -1;
 }
 
+/* ---- N2: routing, matchstr, SQL text ---------------------------------------------------- */
+
+/* one piece of a splittocmd() result: [p, p+n) */
+typedef struct {
+    const uint8_t *p;
+    size_t n;
+} piece;
+
+/* ccmdstr::splittocmd(buffer,sep) with bdelspace=false (public/_public.cpp:274-302): greedy
+ * left-to-right search; the text after the last separator is the last field.  Returns the
+ * number of fields (at most cap are written). */
+static size_t split_pieces(const uint8_t *b, size_t n, const char *sep, piece *out, size_t cap) {
+    size_t sl = strlen(sep), pos = 0, k = 0;
+    for (;;) {
+        size_t p = bytes_find(b, n, (const uint8_t *)sep, sl, pos);
+        if (p == (size_t)-1) break;
+        if (k < cap) {
+            out[k].p = b + pos;
+            out[k].n = p - pos;
+        }
+        ++k;
+        pos = p + sl;
+    }
+    if (k < cap) {
+        out[k].p = b + pos;
+        out[k].n = n - pos;
+    }
+    return k + 1;
+}
+
+/* matchstr, public/_public.cpp:213-263.  Both strings are upper-cased (ASCII); every rule
+ * between commas is cut at '*' and the pieces must occur in order, the first at the start of
+ * the name (:245-246), the last at its end (:249-250: find from length-piece length; that
+ * position wraps when the piece is longer than the name, and nothing is found). */
+int ORC_FN(matchstr)(const char *str, const char *rules) {
+    size_t fl = strlen(str), rl = strlen(rules);
+    if (rl == 0) return 0;
+    if (rl == 1 && rules[0] == '*') return 1;
+    uint8_t *f = (uint8_t *)malloc(fl + 1), *m = (uint8_t *)malloc(rl + 1);
+    memcpy(f, str, fl);
+    memcpy(m, rules, rl);
+    ascii_upper(f, fl);
+    ascii_upper(m, rl);
+    size_t nr = split_pieces(m, rl, ",", NULL, 0);
+    piece *rule = (piece *)malloc(nr * sizeof(piece));
+    split_pieces(m, rl, ",", rule, nr);
+    int hit = 0;
+    for (size_t ii = 0; ii < nr && !hit; ++ii) {
+        if (rule[ii].n == 0) continue; /* :237 */
+        size_t np = split_pieces(rule[ii].p, rule[ii].n, "*", NULL, 0);
+        piece *sub = (piece *)malloc(np * sizeof(piece));
+        split_pieces(rule[ii].p, rule[ii].n, "*", sub, np);
+        size_t pos1 = 0, jj;
+        for (jj = 0; jj < np; ++jj) {
+            const uint8_t *s = sub[jj].p;
+            size_t sn = sub[jj].n;
+            if (jj == 0) { /* filename.substr(0,len) != piece */
+                size_t head = sn < fl ? sn : fl;
+                if (head != sn || memcmp(f, s, sn) != 0) break;
+            }
+            if (jj == np - 1) {
+                if (sn > fl) break; /* wrapped start position: npos */
+                if (bytes_find(f, fl, s, sn, fl - sn) == (size_t)-1) break;
+            }
+            size_t pos2 = bytes_find(f, fl, s, sn, pos1); /* :252 */
+            if (pos2 == (size_t)-1) break;
+            pos1 = pos2 + sn;
+        }
+        if (jj == np) hit = 1;
+        free(sub);
+    }
+    free(rule);
+    free(f);
+    free(m);
+    return hit;
+}
+
+/* value of the char* getxmlbuffer (public/_public.cpp:483-504, len=0: no limit) as the C string
+ * its caller reads: cut at the first NUL, and at cap-1 bytes */
+static void cfield(const uint8_t *rec, size_t reclen, const char *name, char *dst, size_t cap) {
+    size_t p = 0, l = 0;
+    if (!getxml_span(rec, reclen, name, 0, &p, &l)) l = 0; /* str stays empty: "" is copied */
+    const void *z = l ? memchr(rec + p, 0, l) : NULL;
+    if (z) l = (size_t)((const uint8_t *)z - (rec + p));
+    if (l > cap - 1) l = cap - 1;
+    if (l) memcpy(dst, rec + p, l);
+    dst[l] = 0;
+}
+
+/* loadxmltotable, tools/xmltodb.cpp:102-129 */
+int64_t ORC_FN(load_xmltotable)(const uint8_t *data, size_t n, orc_xmltotable *out, int64_t cap) {
+    int64_t nrec = ORC_FN(split_records)(data, n, "<endl/>", NULL, NULL, 0);
+    if (nrec <= 0) return 0;
+    uint64_t *st = (uint64_t *)malloc((size_t)nrec * sizeof(uint64_t));
+    uint64_t *ln = (uint64_t *)malloc((size_t)nrec * sizeof(uint64_t));
+    ORC_FN(split_records)(data, n, "<endl/>", st, ln, nrec);
+    for (int64_t r = 0; r < nrec && r < cap; ++r) {
+        const uint8_t *rec = data + st[r];
+        size_t rl = (size_t)ln[r];
+        orc_xmltotable *e = &out[r];
+        memset(e, 0, sizeof *e); /* :117 */
+        cfield(rec, rl, "filename", e->filename, sizeof e->filename);
+        cfield(rec, rl, "tname", e->tname, sizeof e->tname);
+        size_t p = 0, l = 0; /* :121, the int overload: untouched (0) when it fails */
+        if (getxml_span(rec, rl, "uptbz", 0, &p, &l)) {
+            uint64_t v;
+            if (ORC_FN(convert)(rec + p, l, ORC_T_I32, &v)) e->uptbz = (int)(int64_t)v;
+        }
+        cfield(rec, rl, "execsql", e->execsql, sizeof e->execsql);
+    }
+    free(st);
+    free(ln);
+    return nrec;
+}
+
+/* a growing C string */
+typedef struct {
+    char *p;
+    size_t n, cap;
+} cstr;
+static void cs_add(cstr *s, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+#include <stdarg.h>
+static void cs_add(cstr *s, const char *fmt, ...) {
+    va_list ap, aq;
+    va_start(ap, fmt);
+    va_copy(aq, ap);
+    int need = vsnprintf(NULL, 0, fmt, ap);
+    va_end(ap);
+    if (s->n + (size_t)need + 1 > s->cap) {
+        s->cap = (s->n + (size_t)need + 1) * 2;
+        s->p = (char *)realloc(s->p, s->cap);
+    }
+    vsnprintf(s->p + s->n, (size_t)need + 1, fmt, aq);
+    va_end(aq);
+    s->n += (size_t)need;
+}
+/* deleterchr(str,','), public/_public.cpp:52-59 (same rule as the trim above) */
+static void cs_drop_commas(cstr *s) {
+    if (!s->p) return;
+    s->n = ORC_FN(trim)((uint8_t *)s->p, s->n, ',', 1);
+    s->p[s->n] = 0;
+}
+static void cs_out(const cstr *s, char *dst, size_t cap) {
+    if (!dst || !cap) return;
+    size_t k = s->n < cap - 1 ? s->n : cap - 1;
+    if (k) memcpy(dst, s->p, k);
+    dst[k] = 0;
+}
+
+/* crtsql, tools/xmltodb.cpp:325-419 */
+int ORC_FN(crtsql)(const orc_xmltotable *e, const orc_col *cols, int ncols, char *ins, size_t inscap,
+                   char *upd, size_t updcap) {
+    cstr names = {0, 0, 0}, binds = {0, 0, 0}, sql = {0, 0, 0};
+    cs_add(&names, "%s", "");
+    cs_add(&binds, "%s", "");
+    int colseq = 1;
+    for (int i = 0; i < ncols; ++i) {
+        if (strcmp(cols[i].colname, "upttime") == 0) continue; /* :337 */
+        cs_add(&names, "%s,", cols[i].colname);
+        if (strcmp(cols[i].colname, "keyid") == 0)
+            cs_add(&binds, "SEQ_%s.nextval,", e->tname + 2); /* :345; the array is zeroed */
+        else if (strcmp(cols[i].datatype, "date") == 0)
+            cs_add(&binds, "to_date(:%d,'yyyymmddhh24miss'),", colseq++);
+        else
+            cs_add(&binds, ":%d,", colseq++);
+    }
+    cs_drop_commas(&names);
+    cs_drop_commas(&binds);
+    cs_add(&sql, "insert into %s(%s) values(%s)", e->tname, names.p, binds.p);
+    cs_out(&sql, ins, inscap);
+    free(names.p);
+    free(binds.p);
+    free(sql.p);
+    if (e->uptbz != 1) return 0; /* :365 */
+
+    cstr set = {0, 0, 0}, where = {0, 0, 0}, usql = {0, 0, 0};
+    cs_add(&set, " set ");
+    cs_add(&where, " where 1=1");
+    colseq = 1;
+    for (int i = 0; i < ncols; ++i) {
+        if (cols[i].pkseq != 0) continue;
+        if (strcmp(cols[i].colname, "keyid") == 0) continue;
+        if (strcmp(cols[i].colname, "upttime") == 0)
+            cs_add(&set, "upttime=sysdate,");
+        else if (strcmp(cols[i].datatype, "date") == 0)
+            cs_add(&set, "%s=to_date(:%d,'yyyymmddhh24miss),", cols[i].colname, colseq++); /* :393 as written */
+        else
+            cs_add(&set, "%s=:%d,", cols[i].colname, colseq++);
+    }
+    cs_drop_commas(&set);
+    /* m_vpkcols: the key columns by their position in the key (ties: schema order) */
+    int *pk = (int *)malloc((size_t)(ncols > 0 ? ncols : 1) * sizeof(int)), npk = 0;
+    for (int i = 0; i < ncols; ++i)
+        if (cols[i].pkseq != 0) {
+            int at = npk++;
+            while (at > 0 && cols[pk[at - 1]].pkseq > cols[i].pkseq) {
+                pk[at] = pk[at - 1];
+                --at;
+            }
+            pk[at] = i;
+        }
+    for (int k = 0; k < npk; ++k) { /* :403-414 */
+        const orc_col *c = &cols[pk[k]];
+        if (strcmp(c->datatype, "date") == 0)
+            cs_add(&where, " and %s=to_date(:%d,'yyyymmddhh24miss')", c->colname, colseq++);
+        else
+            cs_add(&where, " and %s=:%d", c->colname, colseq++);
+    }
+    free(pk);
+    cs_add(&usql, "update %s%s%s", e->tname, set.p, where.p);
+    cs_out(&usql, upd, updcap);
+    free(set.p);
+    free(where.p);
+    free(usql.p);
+    return 1;
+}
+
+/* preparesql, tools/xmltodb.cpp:421-477 */
+int ORC_FN(bind_plan)(const orc_xmltotable *e, const orc_col *cols, int ncols, int *ins, int *upd,
+                      int *nupd) {
+    int k = 0, u = 0;
+    for (int i = 0; i < ncols; ++i) { /* :431-442 */
+        if (strcmp(cols[i].colname, "upttime") == 0) continue;
+        if (strcmp(cols[i].colname, "keyid") == 0) continue;
+        ins[k++] = i;
+    }
+    if (e->uptbz == 1) {
+        for (int i = 0; i < ncols; ++i) { /* :453-466 */
+            if (cols[i].pkseq != 0) continue;
+            if (strcmp(cols[i].colname, "keyid") == 0) continue;
+            if (strcmp(cols[i].colname, "upttime") == 0) continue;
+            upd[u++] = i;
+        }
+        for (int i = 0; i < ncols; ++i) /* :469-474 */
+            if (cols[i].pkseq != 0) upd[u++] = i;
+    }
+    if (nupd) *nupd = u;
+    return k;
+}
+
 const char *ORC_FN(kind)(void) { return "port"; }

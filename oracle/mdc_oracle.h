@@ -131,6 +131,35 @@ int64_t ORC_FN(format_xml_files)(const char *const *fieldname, const int *fieldl
                                  const char *bfilename, const char *timestamp,
                                  const char *efilename, int first_seq);
 
+/* N2  routing of a file to its table and the SQL text, tools/xmltodb.cpp:102-129, :311-419.
+ * orc_xmltotable mirrors st_xmltotable (tools/xmltodb.cpp:35-41). */
+typedef struct orc_xmltotable {
+    char filename[128];
+    char tname[32];
+    int uptbz;
+    char execsql[256];
+} orc_xmltotable;
+
+/* matchstr(str,rules), public/_public.cpp:213-263: 1 = match */
+int ORC_FN(matchstr)(const char *str, const char *rules);
+
+/* loadxmltotable over a buffer (tools/xmltodb.cpp:102-129): writes at most cap entries and
+ * returns the number of records.  A value that does not fit its array (undefined behaviour in
+ * the reference, which copies it whole) is cut to the array size minus one. */
+int64_t ORC_FN(load_xmltotable)(const uint8_t *data, size_t n, orc_xmltotable *out, int64_t cap);
+
+/* crtsql (tools/xmltodb.cpp:325-419): NUL-terminated statement texts into ins / upd (cut to the
+ * capacities); upd is written only when e->uptbz == 1.  The key columns of the where part are
+ * taken by ascending pkseq (the order in which the catalogue query fills m_vpkcols).  Returns
+ * 1 when an update statement was written, else 0. */
+int ORC_FN(crtsql)(const orc_xmltotable *e, const orc_col *cols, int ncols, char *ins, size_t inscap,
+                   char *upd, size_t updcap);
+
+/* bind order of preparesql (tools/xmltodb.cpp:421-477): schema column of every placeholder of
+ * the insert and (uptbz == 1 only) the update statement; returns nins, *nupd the other count */
+int ORC_FN(bind_plan)(const orc_xmltotable *e, const orc_col *cols, int ncols, int *ins, int *upd,
+                      int *nupd);
+
 void ORC_FN(batch_free)(orc_batch *b);
 
 /* name of the implementation behind this library */

@@ -28,6 +28,15 @@ class _CCol(ctypes.Structure):
     ]
 
 
+class _CXmlToTable(ctypes.Structure):
+    _fields_ = [
+        ("filename", ctypes.c_char * 128),
+        ("tname", ctypes.c_char * 32),
+        ("uptbz", ctypes.c_int),
+        ("execsql", ctypes.c_char * 256),
+    ]
+
+
 class _CBatch(ctypes.Structure):
     _fields_ = [
         ("rows", ctypes.c_int64),
@@ -113,6 +122,14 @@ class Checker:
         f("format_xml").argtypes = [vp, vp, ci, vp, vp, i64, i64, vp, vp, i64, ctypes.POINTER(i64)]
         f("format_xml_files").restype = i64
         f("format_xml_files").argtypes = [vp, vp, ci, vp, vp, i64, i64] + [ctypes.c_char_p] * 4 + [ci]
+        f("matchstr").restype = ci
+        f("matchstr").argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        f("load_xmltotable").restype = i64
+        f("load_xmltotable").argtypes = [vp, sz, vp, i64]
+        f("crtsql").restype = ci
+        f("crtsql").argtypes = [vp, vp, ci, ctypes.c_char_p, sz, ctypes.c_char_p, sz]
+        f("bind_plan").restype = ci
+        f("bind_plan").argtypes = [vp, vp, ci, vp, vp, ctypes.POINTER(ci)]
         f("batch_free").restype = None
         f("batch_free").argtypes = [pb]
         f("kind").restype = ctypes.c_char_p
@@ -227,6 +244,43 @@ class Checker:
         return self._f("format_xml_files")(c_names, c_len, len(names), c_off, c_dat, rows, maxcount,
                                            outpath.encode(), bfilename.encode(), timestamp.encode(),
                                            efilename.encode(), first_seq)
+
+
+    # -- routing and SQL text -----------------------------------------------------------
+    def matchstr(self, name, rules) -> bool:
+        enc = lambda x: x.encode() if isinstance(x, str) else bytes(x)
+        return bool(self._f("matchstr")(enc(name), enc(rules)))
+
+    def load_xmltotable(self, data: bytes):
+        """[(filename, tname, uptbz, execsql)] of a parameter file, fields as bytes."""
+        data = bytes(data)
+        n = self._f("load_xmltotable")(data, len(data), None, 0)
+        if n < 0:
+            raise RuntimeError("checker could not read the parameter file")
+        arr = (_CXmlToTable * max(1, n))()
+        self._f("load_xmltotable")(data, len(data), arr, n)
+        return [(e.filename, e.tname, e.uptbz, e.execsql) for e in arr[:n]]
+
+    @staticmethod
+    def _entry(entry):
+        e = _CXmlToTable()
+        enc = lambda x: x.encode() if isinstance(x, str) else bytes(x)
+        e.filename, e.tname, e.uptbz, e.execsql = enc(entry[0]), enc(entry[1]), int(entry[2]), enc(entry[3])
+        return e
+
+    def crtsql(self, entry, cols):
+        """(insertsql, updatesql or None) as bytes."""
+        e, cc = self._entry(entry), _ccols(cols)
+        ins, upd = ctypes.create_string_buffer(1 << 16), ctypes.create_string_buffer(1 << 16)
+        has = self._f("crtsql")(ctypes.byref(e), cc, len(cols), ins, len(ins), upd, len(upd))
+        return ins.value, (upd.value if has else None)
+
+    def bind_plan(self, entry, cols):
+        e, cc = self._entry(entry), _ccols(cols)
+        n = max(1, len(cols))
+        ins, upd, nu = (ctypes.c_int * n)(), (ctypes.c_int * n)(), ctypes.c_int(0)
+        ni = self._f("bind_plan")(ctypes.byref(e), cc, len(cols), ins, upd, ctypes.byref(nu))
+        return list(ins[:ni]), list(upd[:nu.value])
 
 
 _cache = {}

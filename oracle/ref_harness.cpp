@@ -8,9 +8,11 @@
  *
  * Everything that computes a result here is a call into namespace idc of the reference:
  * cifile::readline, getxmlbuffer (all overloads), picknumber, ccmdstr, deletel/r/lrchr.
- * The only restated code is the 12-line column loop of splitbuffer
- * (tools/xmltodb.cpp:492-522), because xmltodb.cpp itself needs Oracle OCI headers and
- * libclntsh, which this image does not have.
+ * The only restated code are loops of the tools that need Oracle OCI headers and libclntsh,
+ * which this image does not have: the 12-line column loop of splitbuffer
+ * (tools/xmltodb.cpp:492-522), the fetch loop of tools/dminingoracle.cpp:196-256, and
+ * loadxmltotable / crtsql / preparesql (tools/xmltodb.cpp:102-129, :325-477), each around the
+ * reference's own functions (readline, getxmlbuffer, cofile, sformat, deleterchr, matchstr).
  */
 #include "_public.h" /* -I<reference>/public */
 
@@ -19,6 +21,9 @@
 #include "orc_builder.h"
 
 #include <unistd.h>
+
+#include <algorithm>
+#include <vector>
 
 using namespace idc;
 
@@ -380,6 +385,115 @@ int64_t ref_format_xml(const char *const *fieldname, const int *fieldlen, int nf
     if (file_off && nf < filecap) file_off[nf] = pos;
     if (nfiles) *nfiles = nf;
     return (int64_t)pos;
+}
+
+/* N2.  matchstr is the reference's own.  loadxmltotable, crtsql and preparesql live in
+ * tools/xmltodb.cpp (needs OCI): their loops are restated here around the reference's own
+ * cifile::readline, getxmlbuffer (char* and int forms), sformat and deleterchr. */
+int ref_matchstr(const char *str, const char *rules) { return matchstr(str, rules) ? 1 : 0; }
+
+int64_t ref_load_xmltotable(const uint8_t *data, size_t n, orc_xmltotable *out, int64_t cap) {
+    std::string path = write_tmp(data, n);
+    cifile ifile;
+    if (path.empty() || ifile.open(path) == false) return -1;
+    std::string buffer;
+    int64_t r = 0;
+    /* the char* getxmlbuffer copies a value of any length: room for the whole record, then
+     * the cut to the array that the checker interface defines */
+    std::vector<char> big;
+    while (ifile.readline(buffer, "<endl/>")) {
+        if (r < cap) {
+            orc_xmltotable *e = &out[r];
+            memset(e, 0, sizeof *e);
+            big.assign(buffer.size() + 2, 0);
+            getxmlbuffer(buffer, "filename", big.data());
+            snprintf(e->filename, sizeof e->filename, "%s", big.data());
+            big.assign(buffer.size() + 2, 0);
+            getxmlbuffer(buffer, "tname", big.data());
+            snprintf(e->tname, sizeof e->tname, "%s", big.data());
+            getxmlbuffer(buffer, "uptbz", e->uptbz);
+            big.assign(buffer.size() + 2, 0);
+            getxmlbuffer(buffer, "execsql", big.data());
+            snprintf(e->execsql, sizeof e->execsql, "%s", big.data());
+        }
+        ++r;
+    }
+    ifile.close();
+    unlink(path.c_str());
+    return r;
+}
+
+int ref_crtsql(const orc_xmltotable *e, const orc_col *cols, int ncols, char *ins, size_t inscap, char *upd,
+               size_t updcap) {
+    orc_xmltotable st = *e; /* tname + 2 below wants a non-const array, as the global is */
+    std::vector<orc_col> vallcols(cols, cols + ncols), vpkcols;
+    for (auto &c : vallcols)
+        if (c.pkseq != 0) vpkcols.push_back(c);
+    std::stable_sort(vpkcols.begin(), vpkcols.end(), [](const orc_col &a, const orc_col &b) { return a.pkseq < b.pkseq; });
+
+    std::string cols_, binds;
+    int colseq = 1;
+    for (auto &c : vallcols) {
+        if (strcmp(c.colname, "upttime") == 0) continue;
+        cols_ += sformat("%s,", c.colname);
+        if (strcmp(c.colname, "keyid") == 0)
+            binds += sformat("SEQ_%s.nextval,", st.tname + 2);
+        else if (strcmp(c.datatype, "date") == 0)
+            binds += sformat("to_date(:%d,'yyyymmddhh24miss'),", colseq++);
+        else
+            binds += sformat(":%d,", colseq++);
+    }
+    deleterchr(cols_, ',');
+    deleterchr(binds, ',');
+    std::string insertsql = sformat("insert into %s(%s) values(%s)", st.tname, cols_.c_str(), binds.c_str());
+    if (ins && inscap) snprintf(ins, inscap, "%s", insertsql.c_str());
+    if (st.uptbz != 1) return 0;
+
+    std::string strset = " set ", strwhere = " where 1=1";
+    colseq = 1;
+    for (auto &c : vallcols) {
+        if (c.pkseq != 0) continue;
+        if (strcmp(c.colname, "keyid") == 0) continue;
+        if (strcmp(c.colname, "upttime") == 0)
+            strset += sformat("upttime=sysdate,");
+        else if (strcmp(c.datatype, "date") == 0)
+            strset += sformat("%s=to_date(:%d,'yyyymmddhh24miss),", c.colname, colseq++);
+        else
+            strset += sformat("%s=:%d,", c.colname, colseq++);
+    }
+    deleterchr(strset, ',');
+    for (auto &c : vpkcols) {
+        if (strcmp(c.datatype, "date") == 0)
+            strwhere += sformat(" and %s=to_date(:%d,'yyyymmddhh24miss')", c.colname, colseq++);
+        else
+            strwhere += sformat(" and %s=:%d", c.colname, colseq++);
+    }
+    std::string updatesql = sformat("update %s%s%s", st.tname, strset.c_str(), strwhere.c_str());
+    if (upd && updcap) snprintf(upd, updcap, "%s", updatesql.c_str());
+    return 1;
+}
+
+int ref_bind_plan(const orc_xmltotable *e, const orc_col *cols, int ncols, int *ins, int *upd, int *nupd) {
+    int colseq = 1, u = 0;
+    for (int i = 0; i < ncols; ++i) {
+        if (strcmp(cols[i].colname, "upttime") == 0) continue;
+        if (strcmp(cols[i].colname, "keyid") == 0) continue;
+        ins[colseq++ - 1] = i;
+    }
+    if (e->uptbz == 1) {
+        for (int i = 0; i < ncols; ++i) {
+            if (cols[i].pkseq != 0) continue;
+            if (strcmp(cols[i].colname, "keyid") == 0) continue;
+            if (strcmp(cols[i].colname, "upttime") == 0) continue;
+            upd[u++] = i;
+        }
+        for (int i = 0; i < ncols; ++i) {
+            if (cols[i].pkseq == 0) continue;
+            upd[u++] = i;
+        }
+    }
+    if (nupd) *nupd = u;
+    return colseq - 1;
 }
 
 void ref_batch_free(orc_batch *b) { builder_free(b); }

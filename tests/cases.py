@@ -337,3 +337,73 @@ def format_cases():
         out.append((f"random/{seed}", [f"f{i}" * (1 + i % 3) for i in range(nf)], fl,
                     random_rows(seed, 23 + seed, nf, nul=0.1 * (seed % 3), big=0.05 * seed), [0, 5, 23, 4][seed]))
     return out
+
+
+# ---- routing, matchstr, SQL text -------------------------------------------------------------
+
+def match_cases():
+    """(file name, rules) pairs for matchstr: the samples of the reference's parameter file and
+    usage text, and the corners of its piece-by-piece search."""
+    names = ["ZHOBTCODE_20240519.XML", "ZHOBTMIND_20240519162800_togxpt_1.xml", "zhobtmind_1.XML", "a.xml", "A",
+             "", "abcabc", "SURF_ZH_2024.txt.gz", "x*y", "ab", "aXbXc", "abc.XML.bak"]
+    rules = ["ZHOBTCODE_*.XML", "ZHOBTMIND_*.XML", "*.XML", "*", "", ",", "*,", ",*", "a*", "*a", "a", "A*A", "a*a",
+             "abc*abc", "abc*bc", "*abc*", "ab*ab*ab", "*.xml,*.gz", "zhobtcode_*,zhobtmind_*", "SURF*,,*.XML",
+             "*b*", "a**c", "**", "a*b*c", "a*c*b", "abcabcabc", "x\\*y", ".XML*", "*.XML*", "ZHOBTMIND*_1.XML",
+             "ab,", " ab", "ab*"]
+    return [(n, r) for n in names for r in rules]
+
+
+def ini_cases():
+    """(name, bytes) parameter files for loadxmltotable.  Values stay within the sizes of
+    st_xmltotable (the reference writes beyond its arrays otherwise)."""
+    long_ok = b"F" * 127
+    return [
+        ("ini_xmltodb", INI_XMLTODB + b"\n"),
+        ("ini_no_final_newline", INI_XMLTODB),
+        ("empty", b""),
+        ("only_marks", b"<endl/>\n<endl/>\n\n<endl/>\n"),
+        ("missing_and_odd",
+         b"<filename>A_*.XML,B_*.XML</filename><tname>T_A</tname><uptbz>2</uptbz><endl/>\n"
+         b"<tname>T_NOFILE</tname><uptbz>x1y</uptbz><execsql></execsql><endl/>\n"
+         b"<filename>*.csv</filename><tname></tname><uptbz>-</uptbz><endl/>\n"
+         b"<filename>c</filename><uptbz>99999999999</uptbz><tname>T_BIG</tname><endl/>\n"
+         b"<filename>d</filename><uptbz> +1 </uptbz><tname>T_SIGN</tname><execsql>delete from t where a='<b>'</execsql><endl/>\n"
+         b"</filename>zz<filename>close_first</filename><tname>T_CF</tname><endl/>\n"
+         b"<filename>dup1</filename><filename>dup2</filename><tname>T_D</tname><uptbz>1.5</uptbz><endl/>\n"
+         b"<filename>two\nlines</filename><tname>T_NL</tname><uptbz>1</uptbz>\n<endl/>\n"
+         b"<filename>crlf</filename><tname>T_CR</tname><endl/>\r\n"
+         b"<filename>tail</filename><tname>T_TAIL</tname><endl/>"),
+        ("nul_inside", b"<filename>ab\x00cd</filename><tname>\x00T</tname><uptbz>1</uptbz><execsql>x\x00y</execsql><endl/>\n"),
+        ("max_sizes", b"<filename>" + long_ok + b"</filename><tname>" + b"T" * 31 + b"</tname><uptbz>-2147483648</uptbz>"
+         b"<execsql>" + b"s" * 255 + b"</execsql><endl/>\n"
+         b"<filename>f</filename><tname>t</tname><uptbz>2147483647</uptbz><endl/>\n"
+         b"<filename>g</filename><tname>t</tname><uptbz>2147483648</uptbz><endl/>\n"),
+    ]
+
+
+def sql_cases():
+    """(name, (filename, tname, uptbz, execsql), columns) for crtsql and the bind order."""
+    from dsp_amd import schema
+    mind, code = schema.ZHOBTMIND, schema.ZHOBTCODE
+    rev = [Col(c.colname, c.datatype, c.collen, {1: 2, 2: 1}.get(c.pkseq, 0)) for c in mind]
+    out = []
+    for up in (1, 2, 0):
+        out.append((f"zhobtmind/uptbz={up}", ("ZHOBTMIND_*.XML", "T_ZHOBTMIND1", up, ""), mind))
+        out.append((f"zhobtcode/uptbz={up}", ("ZHOBTCODE_*.XML", "T_ZHOBTCODE1", up, "delete from T_ZHOBTCODE1"), code))
+    out += [
+        ("key_order_reversed", ("x", "T_ZHOBTMIND1", 1, ""), rev),
+        ("one_byte_name", ("x", "T_X", 1, ""), [Col("t", "number", 22)]),
+        ("one_byte_key", ("x", "T_X", 1, ""), [Col("k", "char", 5, 1)]),
+        ("short_tname", ("x", "T", 1, ""), [Col("a", "char", 5, 1), Col("keyid", "number", 22)]),
+        ("empty_tname", ("x", "", 1, ""), [Col("keyid", "number", 22), Col("ab", "date", 14)]),
+        ("only_upttime", ("x", "T_U", 1, ""), [Col("upttime", "date", 14)]),
+        ("no_columns", ("x", "T_N", 1, ""), []),
+        ("date_key_no_set", ("x", "T_DK", 1, ""), [Col("d1", "date", 14, 1), Col("d2", "date", 14, 2)]),
+        ("keyid_first", ("x", "T_KF", 1, ""), [Col("keyid", "number", 22), Col("v", "number", 22), Col("d", "date", 14),
+                                                 Col("upttime", "date", 14), Col("id", "char", 10, 1)]),
+        ("keyid_is_key", ("x", "T_KK", 1, ""), [Col("keyid", "number", 22, 1), Col("v", "char", 3)]),
+        ("upttime_is_key", ("x", "T_UK", 1, ""), [Col("upttime", "date", 14, 1), Col("v", "char", 3)]),
+        ("many", ("x", "T_MANY", 1, ""), [Col(f"c{i}", ("char", "date", "number")[i % 3], 10, 3 - i if i < 3 else 0)
+                                           for i in range(24)]),
+    ]
+    return out

@@ -34,6 +34,26 @@ def test_open_failure_is_code_5_without_touching_the_gpu(exe):
     assert r.returncode == 5 and "cannot open" in r.stderr
 
 
+def test_routing_and_sql_through_the_host_layer(exe, port, tmp_path):
+    import cases
+    ini = tmp_path / "xmltodb.xml"
+    ini.write_bytes(cases.INI_XMLTODB + b"\n")
+    cols = schema.ZHOBTMIND
+    spec = ",".join(f"{c.colname}:{c.datatype}:{c.collen}:0:{c.pkseq}" for c in cols)
+    r = subprocess.run([exe, "route", str(ini), "ZHOBTMIND_20240519162800_togxpt_1.XML", spec], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    entry = port.load_xmltotable(cases.INI_XMLTODB + b"\n")[1]
+    ins, upd = port.crtsql(entry, cols)
+    bi, bu = port.bind_plan(entry, cols)
+    assert r.stdout.splitlines() == [
+        "tname T_ZHOBTMIND1", "uptbz 1", "execsql ", "insert " + ins.decode(), "update " + upd.decode(),
+        "bind_insert " + " ".join(map(str, bi)), "bind_update " + " ".join(map(str, bu))]
+    r = subprocess.run([exe, "route", str(ini), "SURF_ZH.txt", spec], capture_output=True, text=True)
+    assert r.returncode == 1  # no routing entry: _xmltodb()'s code 1
+    r = subprocess.run([exe, "route", str(tmp_path / "none.xml"), "a.xml", spec], capture_output=True, text=True)
+    assert r.returncode == 5
+
+
 def test_usage(exe):
     assert subprocess.run([exe], capture_output=True).returncode == 2
 
