@@ -28,6 +28,7 @@
 namespace mdc {
 hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t stream);
 hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream);
+hipError_t launch_template_kernel(const TileParams &P, hipStream_t stream);
 uint32_t scan_segments(uint32_t ntiles);
 hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt,
                              hipStream_t stream);
@@ -173,6 +174,7 @@ struct mdc_parser {
     uint32_t *d_counts = nullptr;
     uint64_t *d_base = nullptr;
     uint32_t *d_status = nullptr;
+    uint32_t *d_tmpl = nullptr;     // tag template of the current input (see TMPL_MAX)
     uint32_t *d_hdr = nullptr;      // per tile: cell map slot, first record start
     uint32_t *d_cellmap = nullptr;  // (ncols + 1) x map_cap words
     size_t map_cap = 0, map_stride = 0;
@@ -461,6 +463,10 @@ static int parser_finish(mdc_parser *p, const mdc_opts *opts) {
     if (rc) return rc;
     p->d_status = (uint32_t *)st;
     HIP_TRY(hipMemset(p->d_status, 0, 256));
+    rc = dev_alloc(p->dev, (1 + TMPL_MAX) * 16, &st);
+    if (rc) return rc;
+    p->d_tmpl = (uint32_t *)st;
+    HIP_TRY(hipMemset(p->d_tmpl, 0, (1 + TMPL_MAX) * 16));
     HIP_TRY(hipHostMalloc((void **)&p->h_totals, (MAX_COLS + 8) * sizeof(uint64_t), hipHostMallocDefault));
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&p->ev[i]));
     return MDC_OK;
@@ -530,6 +536,7 @@ extern "C" void mdc_parser_destroy(mdc_parser *p) {
         dev_free(p->dev, p->d_counts);
         dev_free(p->dev, p->d_base);
         dev_free(p->dev, p->d_status);
+        dev_free(p->dev, p->d_tmpl);
         dev_free(p->dev, p->d_hdr);
         dev_free(p->dev, p->d_cellmap);
         if (p->h_totals) (void)hipHostFree(p->h_totals);
@@ -660,7 +667,10 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     P.map_cap = (uint32_t)p->map_cap;
     P.map_stride = (uint32_t)p->map_stride;
     P.tile_hdr = p->d_hdr;
+    P.tmpl = p->d_tmpl;
+    P.use_tmpl = p->mode == MODE_XML ? 1u : 0u;
 #ifdef MDC_ABLATE
+    if (getenv("MDC_NO_TEMPLATE")) P.use_tmpl = 0;
     if (const char *dbg = getenv("MDC_DEBUG_SKIP")) P.debug = (uint32_t)atoi(dbg);
 #endif
 
@@ -672,6 +682,7 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
         P.L = p->LSs[p->lb_level];
         HIP_TRY(hipMemsetAsync(p->d_status, 0, 4, s));
         HIP_TRY(hipEventRecord(p->ev[0], s));
+        HIP_TRY(launch_template_kernel(P, s));
         HIP_TRY(launch_tile_kernel(false, P, s));
         HIP_TRY(hipEventRecord(p->ev[1], s));
         HIP_TRY(launch_scan_tiles(p->d_counts, p->d_base, (uint32_t)ntiles, ncnt, s));

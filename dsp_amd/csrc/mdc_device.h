@@ -21,6 +21,16 @@ constexpr int MAX_COLS = 128;
 constexpr int MAX_ENDBZ = 32;
 constexpr int MAX_SEP = 16;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+// Tag template (tagged input): the '<' events of one sample record, in order.  Event k of a
+// record whose events all repeat the sample's tag texts byte for byte matches what sample event
+// k matched, so such a record needs no table lookup.  In memory: 4 words of header (word 0 =
+// number of events, 0 = no template), then one 4-word entry per event: the first 8 bytes of the
+// tag text through '>' (zero beyond it), bytes 8..11, and length | pattern index << 8
+// (TMPL_NOPAT: the sample's event matched no pattern).
+constexpr uint32_t TMPL_MAX = 64;
+constexpr uint32_t TMPL_MAXLEN = 12;
+constexpr uint32_t TMPL_NOPAT = 0xFFFFFFu;
+constexpr uint32_t TMPL_WINDOW = 4096;  // the sample record is the second record of the input and must end in this window
 
 static_assert(TILE == BLOCK * 64, "every lane owns 64 tile bytes");
 static_assert(TILE + LBMAX + 64 <= 32768, "cell descriptors hold 15-bit LDS indices");
@@ -133,6 +143,8 @@ struct TileParams {
     uint32_t map_stride;         // record slots per tile: tile t owns [t * map_stride, (t + 1) * map_stride)
     uint32_t *tile_hdr;          // [ntiles][2]: slot (NONE = not mapped), first record start | has_nul << 31
     uint32_t only_unmapped;      // write kernel: leave the mapped tiles to the emit kernel
+    uint32_t *tmpl;              // tag template (always a valid pointer; word 0 == 0: none)
+    uint32_t use_tmpl;           // tagged input: the sizing pass may use the template
     uint32_t debug;  // diagnostic builds only: phases to skip (ablation timing)
 };
 

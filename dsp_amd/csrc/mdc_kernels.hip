@@ -72,16 +72,21 @@ __device__ __forceinline__ uint32_t mask16_eq(const uint4 &v, uint32_t pat4) {
 
 __device__ __forceinline__ uint32_t rep4(uint32_t b) { return b * 0x01010101u; }
 
-// inclusive prefix sum across the 64 lanes of a wave
+// inclusive prefix sum across the 64 lanes of a wave, in the data-parallel-primitive form of the
+// vector adds (no LDS traffic): four shifts inside every row of 16 lanes, then the last lane of
+// row 0 and row 2 is added to the row above, then lane 31 to the upper half.  A lane without a
+// source (shifted in from outside its row, or in a row the mask leaves out) adds 0.
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
     return v;
 }
+// the value of the wave's last lane
+__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 
 // Walks the bytes of one cell's source through the cell's filter.  EMIT=false measures the
 // cell (and feeds the number parser); EMIT=true writes the surviving bytes to dst.
@@ -172,6 +177,7 @@ enum {
     MS_LBCNT = 3,   // events found in the look-behind region
     MS_WTOT = 4,    // 4 words: per-wave totals of the rank/event scan
     MS_NOMAP = 9,   // sizing pass: a cell does not fit a map word
+    MS_IRR = 10,    // sizing pass: a record of the tile does not follow the tag template
     MS_COUNT = 16
 };
 
@@ -310,6 +316,174 @@ __device__ __forceinline__ void match_tag(const uint8_t *sdata, const SchemaHdr 
     const uint32_t slot = tag_slot(H, k);
     const uint4 e0 = *(const uint4 *)&ht[slot];
     tag_apply(sdata, cols, ht, q, k, slot, e0, evt, rl, RB);
+}
+
+// The same lookup without side effects: how many patterns the '<' at LDS index q matches, and for
+// the last of them idx = 2 * column + kind and L = length of the tag text through '>'.
+__device__ __forceinline__ uint32_t tag_lookup(const uint8_t *sdata, const SchemaHdr *H, const DevCol *cols,
+                                               const HtEntry *ht, uint32_t q, uint32_t &idx, uint32_t &L) {
+    const TagKey k = tag_key(sdata, q);
+    uint32_t slot = tag_slot(H, k);
+    const HtEntry &f = ht[slot];
+    if (!(f.meta >> 31) || f.klo != k.lo || f.khi != k.hi) return 0;
+    const uint32_t a = q + 1;
+    uint32_t n = 0;
+    for (;;) {
+        const HtEntry &e = ht[slot];
+        const uint32_t meta = e.meta;
+        const uint32_t tlen = meta & 0xFFu, kind = (meta >> 8) & 1u, col = (meta >> 16) & 0x3FFFu;
+        bool ok = true;
+        if (tlen >= 8) {
+            const uint64_t w2 = lds_u64(sdata + a + 8);
+            ok = (((uint32_t)w2 ^ e.k2lo) & e.m2lo) == 0 && (((uint32_t)(w2 >> 32) ^ e.k2hi) & e.m2hi) == 0;
+            if (ok && (meta & 0x40000000u)) {
+                const uint8_t *nm = cols[col].name;
+                for (uint32_t k2 = 16; k2 < tlen; ++k2)
+                    if (sdata[a + k2] != nm[k2 - kind]) {
+                        ok = false;
+                        break;
+                    }
+                if (ok && sdata[a + tlen] != '>') ok = false;
+            }
+        }
+        if (ok) {
+            ++n;
+            idx = 2 * col + kind;
+            L = tlen + 1;
+        }
+        slot = e.next;
+        if (!slot) break;
+    }
+    return n;
+}
+
+// Event k of a record against entry k of the tag template: the tag text through '>' must repeat
+// the sample's byte for byte; then the event matches what the sample's did, and its position goes
+// to first_pos[pattern][record] with a plain store (in a record that repeats the sample no
+// pattern occurs twice).  false = the record does not follow the template.
+__device__ __forceinline__ bool tmpl_event(const uint8_t *sdata, const uint4 *tl, uint32_t nT, uint32_t q, uint32_t k,
+                                           uint32_t *evt, uint32_t rl, uint32_t RB) {
+    if (k >= nT) return false;
+    const uint4 t = tl[k];
+    const uint64_t w = lds_u64(sdata + q + 1);
+    uint32_t w2;
+    __builtin_memcpy(&w2, sdata + q + 9, 4);
+    const uint32_t L = t.w & 0xFFu, idx = t.w >> 8;  // 1 <= L <= TMPL_MAXLEN
+    const uint32_t n1 = L < 8 ? L : 8;
+    const uint64_t m1 = ~0ull >> (64 - 8 * n1);
+    const uint32_t m2 = L > 8 ? 0xFFFFFFFFu >> (32 - 8 * (L - 8)) : 0u;
+    const uint64_t key = (uint64_t)t.x | ((uint64_t)t.y << 32);
+    const bool ok = (((w ^ key) & m1) == 0) & (((w2 ^ t.z) & m2) == 0);
+    if (ok && idx != TMPL_NOPAT) ((uint16_t *)evt)[idx * RB + rl] = (uint16_t)q;
+    return ok;
+}
+
+// Builds the tag template from the second record of the input (the first one that starts right
+// behind a terminator).  One wave; lane l looks at bytes [64 l, 64 l + 64) of the first
+// TMPL_WINDOW bytes.  No template (word 0 = 0) when the window holds no two terminators, the
+// record has no or too many '<', a tag text is longer than TMPL_MAXLEN or holds a newline, an
+// event matches two patterns or two events match the same one.
+__global__ __launch_bounds__(64) void template_kernel(const TileParams P) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ int tpos[2];
+    __shared__ uint32_t seen[2 * MAX_COLS / 32], bad;
+    const int lane = threadIdx.x;
+    const uint32_t sb = (P.schema_bytes + 15) & ~15u;
+    uint8_t *win = smem + sb;
+    for (uint32_t i = lane; i < P.schema_bytes / 16; i += 64) ((uint4 *)smem)[i] = ((const uint4 *)P.schema)[i];
+    const uint32_t nwin = P.n < TMPL_WINDOW ? (uint32_t)P.n : TMPL_WINDOW;
+    for (uint32_t i = lane; i < TMPL_WINDOW + 64; i += 64) win[i] = i < nwin ? P.data[i] : 0;
+    if (lane < 2) tpos[lane] = -1;
+    if (lane < 2 * MAX_COLS / 32) seen[lane] = 0;
+    if (lane == 0) bad = 0;
+    __syncthreads();
+    const SchemaHdr *H = (const SchemaHdr *)smem;
+    const DevCol *cols = (const DevCol *)(H + 1);
+    const HtEntry *ht = (const HtEntry *)((const uint8_t *)cols + ((H->ncols * sizeof(DevCol) + 15) & ~15u));
+    const int el = (int)H->endbz_len;
+    uint64_t tm = 0, em = 0;
+    for (int b = 0; b < 64; ++b) {
+        const int p = lane * 64 + b;
+        if (p >= (int)nwin) break;
+        const uint8_t c = win[p];
+        if (c == '<') em |= 1ull << b;
+        if (c == '\n') {
+            bool t = p - el >= 0;
+            for (int k = 0; t && k < el; ++k) t = win[p - el + k] == H->endbz[k];
+            if (t) tm |= 1ull << b;
+        }
+    }
+    {
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(tm);
+        uint32_t rank = wave_incl_scan(cnt) - cnt;
+        uint64_t t = tm;
+        while (t && rank < 2) {
+            const int b = __builtin_ctzll(t);
+            t &= t - 1;
+            tpos[rank++] = lane * 64 + b;
+        }
+    }
+    __syncthreads();
+    const int t0 = tpos[0], t1 = tpos[1];
+    if (t1 < 0) {
+        if (lane == 0) P.tmpl[0] = 0;
+        return;
+    }
+    // the record's events: '<' at positions in (t0, t1)
+    {
+        const int lo = t0 + 1 - lane * 64, hi = t1 - lane * 64;  // window of this lane's bits: [lo, hi)
+        uint64_t keep = ~0ull;
+        if (lo >= 64 || hi <= 0)
+            keep = 0;
+        else {
+            if (lo > 0) keep &= ~0ull << lo;
+            if (hi < 64) keep &= ~(~0ull << hi);
+        }
+        em &= keep;
+    }
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(em);
+    const uint32_t incl = wave_incl_scan(cnt);
+    const uint32_t nT = wave_last(incl);
+    uint32_t k = incl - cnt;
+    if (nT == 0 || nT > TMPL_MAX) {
+        if (lane == 0) P.tmpl[0] = 0;
+        return;
+    }
+    while (em) {
+        const int b = __builtin_ctzll(em);
+        em &= em - 1;
+        const uint32_t q = (uint32_t)(lane * 64 + b);
+        uint32_t idx = TMPL_NOPAT, L = 0;
+        const uint32_t nm = tag_lookup(win, H, cols, ht, q, idx, L);
+        if (nm > 1) bad = 1;
+        if (nm == 0) {  // no pattern: the text through the first '>' of the eight bytes behind '<'
+            idx = TMPL_NOPAT;
+            L = 0;
+            for (uint32_t i = 0; i < 8 && !L; ++i)
+                if (win[q + 1 + i] == '>') L = i + 1;
+        } else {
+            const uint32_t old = atomicOr(&seen[idx >> 5], 1u << (idx & 31));
+            if (old & (1u << (idx & 31))) bad = 1;
+        }
+        if (L == 0 || L > TMPL_MAXLEN) {
+            bad = 1;
+            L = 1;
+        }
+        uint32_t w[3] = {0, 0, 0};
+        for (uint32_t i = 0; i < L; ++i) {
+            const uint32_t c = win[q + 1 + i];
+            if (c == '\n') bad = 1;
+            w[i >> 2] |= c << (8 * (i & 3));
+        }
+        uint32_t *e = P.tmpl + 4 + 4 * k;
+        e[0] = w[0];
+        e[1] = w[1];
+        e[2] = w[2];
+        e[3] = L | (idx << 8);
+        ++k;
+    }
+    __syncthreads();
+    if (lane == 0) P.tmpl[0] = bad ? 0 : nT;
 }
 
 // Cells longer than 16 source bytes: filter only (length, or the surviving bytes).  Their
@@ -644,6 +818,8 @@ struct CellEnv {
     uint8_t *wstage;  // this wave's staging area for cell bytes
     uint32_t wstage_cap;
     bool nostore = false;  // diagnostic builds: measure without the column's stores
+    uint32_t dbg = 0;      // diagnostic builds: 64 no conversion, 128 cells not staged, 256 staged but not copied out,
+                           // 512 no value/offset stores
 };
 
 // pointers known to address global memory (a pointer that comes out of a table in memory is
@@ -690,7 +866,10 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
             const uint32_t s = cs_[ps], len = cl_[ps], lvl = cv_[ps];
             const bool found = fd_[ps];
             const bool convert = typed != T_NONE && (found || E.nulcut);
-            const uint32_t ty = (WRITE && convert) ? typed : (uint32_t)T_NONE;  // sizing needs lengths only
+            uint32_t ty = (WRITE && convert) ? typed : (uint32_t)T_NONE;  // sizing needs lengths only
+#ifdef MDC_ABLATE
+            if (E.dbg & 64) ty = T_NONE;
+#endif
             uint64_t value = 0;
             bool valid = false, later = false;
             if (len <= 16) {
@@ -713,7 +892,11 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
                 if (ty != T_NONE) deferred = true;  // value and valid bit come from the second stage
             }
             if (WRITE && convert && valid) atomicOr(&E.vmask[r * E.W + (c >> 5)], 1u << (c & 31));
+#ifdef MDC_ABLATE
+            if (valp && !(E.dbg & 512)) valp[rowbase + r] = value;
+#else
             if (valp) valp[rowbase + r] = value;
+#endif
         }
         const uint32_t incl = wave_incl_scan(flen);
         clo_[ps] = elo;
@@ -721,7 +904,7 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
         cfast_[ps] = fast;
         cf_[ps] = flen;
         cx_[ps] = total + incl - flen;
-        total += __shfl(incl, 63, 64);
+        total += wave_last(incl);
     }
     if (WRITE && !E.nostore) {
         const uint32_t a = (uint32_t)(gb & 15);
@@ -755,8 +938,14 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
                 }
             }
         };
+#ifdef MDC_ABLATE
+        if (E.dbg & 128) return total;
+#endif
         if (staged) {
             put_cells(E.wstage + a);
+#ifdef MDC_ABLATE
+            if (E.dbg & 256) return total;
+#endif
             if (total) {
                 // the wave's own LDS writes are visible to it in program order
                 gmem_u8 *dst = bytesp + gb;
@@ -814,6 +1003,15 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         return make_uint4(w[0], w[1], w[2], w[3]);
     };
 
+    // event index at the start of every record of the batch (entry 0: minus the events of the
+    // tile's first record that lie in the look-behind), then the template's entries
+    int16_t *e0t = (int16_t *)(smem + L.vmask);
+    const uint32_t e0_bytes = ((L.RB + 2) * 2 + 15) & ~15u;
+    uint4 *tmpl_l = (uint4 *)(smem + L.vmask + e0_bytes);
+    const uint32_t tmpl_room = L.coltot - L.vmask > e0_bytes ? (L.coltot - L.vmask - e0_bytes) / 16 : 0;
+    const uint32_t tmpl_cap = tmpl_room < TMPL_MAX ? tmpl_room : TMPL_MAX;
+    const uint32_t nT_in = P.tmpl[0];
+
     // ---- A. coalesced 16-byte loads of the tile, the first look-behind window and the schema.
     // Every load is requested before the first one is waited for; for that no load may stand
     // behind a branch (the compiler waits at the end of a branch for what was loaded in it), so
@@ -845,10 +1043,14 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             lbv = lbmine ? load_chunk(jlb) : make_uint4(0, 0, 0, 0);
         }
         const uint4 sv = g[(uint32_t)tid < sch16 ? tid : 0];
+        // tag template (sizing pass of tagged input): entry k sits behind the event-index array
+        // in the space of the two row masks, which that pass does not use
+        const uint4 tq = ((const uint4 *)P.tmpl)[(uint32_t)tid <= TMPL_MAX ? tid : 0];
 #pragma unroll
         for (int k = 0; k < 4; ++k) ((uint4 *)sdata)[ts_li / CHUNK + k * BLOCK + tid] = tv[k];
         if (lbmine) ((uint4 *)sdata)[jlb] = lbv;
         if ((uint32_t)tid < sch16) s[tid] = sv;
+        if (!WRITE && P.use_tmpl && tid >= 1 && (uint32_t)tid <= tmpl_cap) tmpl_l[tid - 1] = tq;
         for (uint32_t i = tid + BLOCK; i < sch16; i += BLOCK) s[i] = g[i];
         if (tid < MS_COUNT) ms[tid] = tid == MS_LAST ? NONE : 0;
     }
@@ -862,6 +1064,9 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     // delimited mode, sizing pass, one-byte separator: separators are collected like tag events
     // and the field descriptors are made in parallel (otherwise: one lane walks each record)
     const bool sepfast = csv && !WRITE && H->sep_len == 1 && H->sep[0] < 0x80;
+    // tagged input, sizing pass: records that repeat the sample record's tags take the template
+    const bool tmode = !WRITE && !csv && P.use_tmpl && nT_in != 0 && nT_in <= tmpl_cap;
+    const uint32_t nT = nT_in;
     uint32_t *coltot = (uint32_t *)(smem + L.coltot);  // totals of the current batch
     uint32_t *tiletot = coltot + (ncols + 1);          // totals of the batches done so far
     for (uint32_t c = tid; c < ncols + 1; c += BLOCK) tiletot[c] = 0;
@@ -998,16 +1203,36 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         }
     }
     const int jlb0 = s0_li / CHUNK, jlb1 = ts_li / CHUNK;  // look-behind chunks of the first record
+    // template mode: the first record's '<' in the look-behind, one chunk per lane of wave 0, counted
+    // so that every one of them knows its place among the record's events
+    uint32_t lbm = 0, lbk = 0;
+    bool irregular = false;  // (block-uniform) a record of the tile does not follow the template
+    if (tmode) {
+        if (jlb1 - jlb0 > 64) {
+            irregular = true;
+        } else if (wave == 0) {
+            const int j = jlb0 + lane;
+            if (j < jlb1) {
+                lbm = mask16_eq(((const uint4 *)sdata)[j], 0x3C3C3C3Cu);
+                if (j * CHUNK < s0_li) lbm &= ~0u << (s0_li - j * CHUNK);
+            }
+            const uint32_t cnt = (uint32_t)__builtin_popcount(lbm);
+            const uint32_t incl = wave_incl_scan(cnt);
+            lbk = incl - cnt;
+            if (lane == 63) e0t[0] = (int16_t)(-(int)incl);
+        }
+    }
     STAMP(1);  // classify + rank scan
 
     // ---- batches of RB records
     for (uint32_t rb0 = 0; rb0 < nrec; rb0 += RB) {
         const uint32_t RBn = (nrec - rb0 < RB) ? nrec - rb0 : RB;
         for (uint32_t i = tid; i < (RB * npat + 1) / 2; i += BLOCK) evt[i] = NONE;
-        for (uint32_t i = tid; i < RB * W; i += BLOCK) {
-            vmask[i] = 0;
-            fmask[i] = 0;
-        }
+        if (WRITE || csv)  // (the sizing pass of tagged input keeps the tag template there)
+            for (uint32_t i = tid; i < RB * W; i += BLOCK) {
+                vmask[i] = 0;
+                fmask[i] = 0;
+            }
         // terminator positions of this batch
         {
             uint64_t t = tm;
@@ -1019,6 +1244,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 // the record behind this terminator starts with the separators that follow it
                 if (fastcsv && r + 1 >= rb0 && r + 1 <= rb0 + RBn)
                     e0[r + 1 - rb0] = ev_base + (uint32_t)__builtin_popcountll(em & ((1ull << b) - 1));
+                if (tmode && r + 1 >= rb0 && r + 1 <= rb0 + RBn)
+                    e0t[r + 1 - rb0] = (int16_t)(ev_base + (uint32_t)__builtin_popcountll(em & ((1ull << b) - 1)));
                 ++r;
             }
             if (fastcsv && rb0 == 0 && tid == 0) e0[0] = 0;
@@ -1026,7 +1253,49 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         __syncthreads();
         STAMP(2);  // clears
 
-        if (!csv && !SKIP(1)) {
+        bool general = !csv && !SKIP(1);
+        if (tmode && general && !irregular) {
+            // ---- C/D with the tag template.  Every record must have as many '<' as the sample ...
+            if ((uint32_t)tid < RBn && (uint32_t)((int)e0t[tid + 1] - (int)e0t[tid]) != nT) ms[MS_IRR] = 1;
+            bool ok = true;
+            // ... and event k must repeat the sample's event k: the first record's events in the
+            // look-behind (first batch only) ...
+            if (rb0 == 0 && wave == 0) {
+                uint32_t m = lbm, k = lbk;
+                while (m) {
+                    const uint32_t b = __builtin_ctz(m);
+                    m &= m - 1;
+                    ok &= tmpl_event(sdata, tmpl_l, nT, (uint32_t)((jlb0 + lane) * CHUNK) + b, k++, evt, 0, RB);
+                }
+            }
+            // ... and this lane's own: one walk over its '<' and terminators keeps the record and
+            // the event's place in it
+            {
+                uint64_t x = em | tm;
+                uint32_t r = rank_base;
+                uint32_t k = (r >= rb0 && r <= rb0 + RBn) ? (uint32_t)((int)ev_base - (int)e0t[r - rb0]) : 0u;
+                while (x) {
+                    const int b = __builtin_ctzll(x);
+                    x &= x - 1;
+                    if ((tm >> b) & 1) {
+                        ++r;
+                        k = 0;
+                    } else {
+                        if (r >= rb0 && r < rb0 + RBn) ok &= tmpl_event(sdata, tmpl_l, nT, (uint32_t)(my_li + b), k, evt, r - rb0, RB);
+                        ++k;
+                    }
+                }
+            }
+            if (!ok) ms[MS_IRR] = 1;
+            __syncthreads();
+            irregular = ms[MS_IRR] != 0;  // (nobody writes the flag again before the next barrier)
+            general = irregular;
+            if (general) {  // some record differs: the whole tile goes through the table lookup
+                for (uint32_t i = tid; i < (RB * npat + 1) / 2; i += BLOCK) evt[i] = NONE;
+                __syncthreads();
+            }
+        }
+        if (general) {
             // ---- C. the first record's events in the look-behind region (first batch only)
             if (rb0 == 0) {
                 for (int j = jlb0 + tid; j < jlb1; j += BLOCK) {
@@ -1305,7 +1574,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         }
         __syncthreads();
         STAMP(9);  // row outputs
-        if (tid == 0) recend[0] = recend[RBn];
+        if (tid == 0) {
+            recend[0] = recend[RBn];
+            if (tmode) e0t[0] = e0t[RBn];
+        }
         __syncthreads();
     }
 
@@ -1482,6 +1754,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     E.wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
     E.wstage_cap = L.stage_cap / (BLOCK / 64);
     E.nostore = SKIP(32);
+#ifdef MDC_ABLATE
+    E.dbg = P.debug;
+#endif
     bool deferred = false;
     for (uint32_t rb0 = 0; rb0 < nrec; rb0 += RB) {
         const uint32_t RBn = (nrec - rb0 < RB) ? nrec - rb0 : RB;
@@ -1663,6 +1938,13 @@ hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream) {
     if (const char *e = getenv("MDC_DEBUG_LDS")) lds = (uint32_t)atoi(e);  // occupancy experiments
 #endif
     hipLaunchKernelGGL(emit_kernel, dim3(P.ntiles), dim3(BLOCK), lds, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_template_kernel(const TileParams &P, hipStream_t stream) {
+    if (P.ntiles == 0 || !P.use_tmpl) return hipSuccess;
+    const uint32_t lds = ((P.schema_bytes + 15) & ~15u) + TMPL_WINDOW + 64;
+    hipLaunchKernelGGL(template_kernel, dim3(1), dim3(64), lds, stream, P);
     return hipGetLastError();
 }
 
