@@ -652,8 +652,9 @@ __device__ __forceinline__ void win_keep(uint64_t &lo, uint64_t &hi, uint32_t n)
 }
 // four decimal digit values in the bytes of w (byte 0 most significant) -> 0..9999
 __device__ __forceinline__ uint32_t parse4(uint32_t w) {
-    const uint32_t t = __umul24(w & 0x000F000Fu, 10u) + ((w >> 8) & 0x000F000Fu);
-    return __umul24(t & 0xFFFFu, 100u) + (t >> 16);
+    // byte-wise dot products: tens and units of the two pairs
+    const uint32_t d = w & 0x0F0F0F0Fu;
+    return __umul24(__builtin_amdgcn_udot4(d, 0x0000010Au, 0u, false), 100u) + __builtin_amdgcn_udot4(d, 0x010A0000u, 0u, false);
 }
 
 // Returns false when the cell needs the general path.  On success: flen = cell length, (elo,
@@ -1268,23 +1269,27 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                     ok &= tmpl_event(sdata, tmpl_l, nT, (uint32_t)((jlb0 + lane) * CHUNK) + b, k++, evt, 0, RB);
                 }
             }
-            // ... and this lane's own: one walk over its '<' and terminators keeps the record and
-            // the event's place in it
+            // ... and this lane's own: one walk over its '<' and terminators (32 bytes at a time:
+            // the bit searches stay in one register) keeps the record and the event's place in it
             {
-                uint64_t x = em | tm;
-                uint32_t r = rank_base;
-                uint32_t k = (r >= rb0 && r <= rb0 + RBn) ? (uint32_t)((int)ev_base - (int)e0t[r - rb0]) : 0u;
-                while (x) {
-                    const int b = __builtin_ctzll(x);
-                    x &= x - 1;
-                    if ((tm >> b) & 1) {
-                        ++r;
-                        k = 0;
-                    } else {
-                        if (r >= rb0 && r < rb0 + RBn) ok &= tmpl_event(sdata, tmpl_l, nT, (uint32_t)(my_li + b), k, evt, r - rb0, RB);
-                        ++k;
+                uint32_t rl = rank_base - rb0;  // record within the batch (wraps below it: never < RBn then)
+                uint32_t k = rl <= RBn ? (uint32_t)((int)ev_base - (int)e0t[rl]) : 0u;
+                auto walk = [&](uint32_t xe, uint32_t xt, uint32_t li) {
+                    uint32_t x = xe | xt;
+                    while (x) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(x);
+                        x &= x - 1;
+                        if ((xt >> b) & 1) {
+                            ++rl;
+                            k = 0;
+                        } else {
+                            if (rl < RBn) ok &= tmpl_event(sdata, tmpl_l, nT, li + b, k, evt, rl, RB);
+                            ++k;
+                        }
                     }
-                }
+                };
+                walk((uint32_t)em, (uint32_t)tm, (uint32_t)my_li);
+                walk((uint32_t)(em >> 32), (uint32_t)(tm >> 32), (uint32_t)my_li + 32);
             }
             if (!ok) ms[MS_IRR] = 1;
             __syncthreads();
