@@ -717,9 +717,8 @@ __device__ __forceinline__ bool cell_fast(uint64_t lo, uint64_t hi, uint32_t len
     if (DL == 0) return ok;                        // no digit: the reference overload returns false
     const uint32_t nd = (uint32_t)__builtin_popcount(DL);
     const uint32_t k10 = dotp < 16 ? (uint32_t)__builtin_popcount(DL >> (dotp + 1)) : 0u;
-    // the digits, contiguous from byte 0
+    // the digits, contiguous from byte 0 (what follows them leaves the window in the shift below)
     uint64_t xlo = lo, xhi = hi;
-    win_keep(xlo, xhi, stop < len ? stop : len);
     if (e2 & (p2 < stop)) win_remove(xlo, xhi, p2);
     if (e1 & (p1 < stop)) win_remove(xlo, xhi, p1);
     // right-align the nd digits in a 16-digit field and convert four at a time
@@ -767,6 +766,85 @@ __device__ __forceinline__ bool cell_fast(uint64_t lo, uint64_t hi, uint32_t len
         break;
     }
     return ok;
+}
+
+// The straight-line path for a whole wave of plain cells.  A cell is plain when it has at most 16
+// source bytes that are digits, one sign in front and one decimal point (every well-formed number
+// and date), or when it is an untyped text cell of that length.  Everything is computed without a
+// per-lane branch; the caller takes the results only when all lanes of the pass report true, and
+// runs the general code otherwise.  `typed` is the same for the whole wave.
+__device__ __forceinline__ bool cell_simple(const uint4 &w4, uint32_t len, uint32_t lvl, uint32_t typed, bool convert,
+                                            const double *p10, uint32_t &flen, uint64_t &elo, uint64_t &ehi,
+                                            uint64_t &value, bool &valid) {
+    const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
+    const uint64_t hi = (uint64_t)w4.z | ((uint64_t)w4.w << 32);
+    const uint32_t lenc = len < 16 ? len : 16;
+    const uint32_t Lm = (1u << lenc) - 1;
+    const uint32_t D16 = digit_mask16(w4);
+    const uint32_t D = D16 & Lm, N = ~D16 & Lm;
+    const uint32_t c0 = (uint32_t)lo & 0xFFu;
+    const uint32_t sg = N & (uint32_t)((c0 == '+') | (c0 == '-'));  // 1: a sign in front
+    const uint32_t N1 = N & ~sg;                                     // the other bytes that are no digits
+    const uint32_t p = (uint32_t)__builtin_ctz(N1 | 0x10000u);       // the first of them (16: none)
+    const uint32_t cp = win_byte(lo, hi, p & 15);
+    const uint32_t nd = (uint32_t)__builtin_popcount(D);
+    const bool isdate = lvl == LVL_DATE;
+    bool simple = (len <= 16) & ((N1 & (N1 - 1)) == 0) & ((N1 == 0) | (cp == '.')) & !(isdate & (sg != 0));
+    if (typed == T_F64) simple &= nd <= 15;  // (more digits may pass 2^53: the second stage divides exactly)
+    if (typed == T_NONE) simple |= (lvl == LVL_CHAR) & (len <= 16);
+    // the window without the decimal point (p == 16: as it is)
+    const uint64_t slo = (lo >> 8) | (hi << 56), shi = hi >> 8;
+    const uint32_t pl = p < 8 ? p : 8, ph = p < 8 ? 0 : p - 8;  // bytes kept in place in either half
+    const uint64_t klo = pl < 8 ? ~(~0ull << (8 * pl)) : ~0ull;
+    const uint64_t khi = ph < 8 ? ~(~0ull << (8 * ph)) : ~0ull;
+    const uint64_t xlo = (lo & klo) | (slo & ~klo), xhi = (hi & khi) | (shi & ~khi);
+    // (plain: apart from the digits there are only the sign and the point, which the number level
+    // keeps; the date level keeps the digits)
+    flen = isdate ? nd : len;
+    elo = isdate ? xlo : lo;
+    ehi = isdate ? xhi : hi;
+    value = 0;
+    valid = false;
+    if (typed == T_NONE) return simple;
+    // the digits right-aligned in 16 bytes (the sign's byte cleared, what follows the digits
+    // leaves at the top), four at a time to a number
+    const bool keep = !isdate;  // the date level has taken sign and point away before the conversion
+    const uint64_t zlo = xlo & ~(uint64_t)(0xFFu & (0u - sg));
+    const uint32_t sh = 8 * (16 - nd - sg);
+    const uint64_t up = (sh & 64) ? zlo : xhi, dn = (sh & 64) ? 0ull : zlo;
+    const uint32_t t = sh & 63;
+    const uint64_t yhi = (sh & 128) ? 0ull : (up << t) | (t ? dn >> (64 - t) : 0ull);
+    const uint64_t ylo = (sh & 128) ? 0ull : dn << t;
+    const uint32_t hi8 = parse4((uint32_t)ylo) * 10000u + parse4((uint32_t)(ylo >> 32));
+    const uint32_t lo8 = parse4((uint32_t)yhi) * 10000u + parse4((uint32_t)(yhi >> 32));
+    const uint64_t m = (uint64_t)hi8 * 100000000ull + lo8;
+    const bool issigned = (typed == T_I32) | (typed == T_I64) | (typed == T_F64);
+    const bool neg = keep & issigned & (sg != 0) & (c0 == '-');
+    bool ok = nd != 0;
+    uint64_t v;
+    switch (typed) {
+    case T_I32:
+        ok &= m <= (neg ? 0x80000000ull : 0x7fffffffull);
+        v = neg ? (uint64_t)(-(int64_t)m) : m;
+        break;
+    case T_U32:
+        ok &= m <= 0x7fffffffull;
+        v = m;
+        break;
+    case T_I64:
+    case T_U64:  // at most 16 digits: always in range
+        v = neg ? (uint64_t)0 - m : m;
+        break;
+    default: {  // T_F64: both operands exact (fewer than 16 digits, at most 15 behind the point): one rounding
+        const uint32_t k10 = keep ? (uint32_t)__builtin_popcount(D >> (p + 1)) : 0u;
+        const double x = (double)m / p10[k10];
+        v = (uint64_t)__double_as_longlong(x) | (neg ? 1ull << 63 : 0ull);
+        break;
+    }
+    }
+    valid = ok & convert;
+    value = valid ? v : 0;
+    return simple;
 }
 
 // stores the first n (<= 16) bytes of the window at dst with at most five unaligned stores
@@ -818,6 +896,7 @@ struct CellEnv {
     uint32_t *vmask;
     uint8_t *wstage;  // this wave's staging area for cell bytes
     uint32_t wstage_cap;
+    bool plain_ok = false; // no NUL cut in this tile: passes of plain cells may take the straight-line path
     bool nostore = false;  // diagnostic builds: measure without the column's stores
     uint32_t dbg = 0;      // diagnostic builds: 64 no conversion, 128 cells not staged, 256 staged but not copied out,
                            // 512 no value/offset stores
@@ -863,7 +942,34 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
         uint32_t flen = 0;
         uint64_t elo = 0, ehi = 0;
         bool fast = false;
-        if (r < RBn) {
+        uint64_t value = 0;
+        bool valid = false;
+        // a whole pass of plain cells takes the straight-line path
+        bool plain = false;
+        if (WRITE && E.plain_ok) {
+            uint32_t tyu = (typed == T_F32 || typed == T_BOOL) ? (uint32_t)T_NONE : typed;
+#ifdef MDC_ABLATE
+            if (E.dbg & 64) tyu = T_NONE;
+#endif
+            tyu = (uint32_t)__builtin_amdgcn_readfirstlane((int)tyu);  // (the wave's, in a scalar register)
+            const bool act = r < RBn;
+            const uint4 w4 = lds_u128(sdata + cs_[ps]);  // (a lane without a record reads the image's first bytes)
+            const bool sc = cell_simple(w4, act ? cl_[ps] : 0u, cv_[ps], tyu, tyu != T_NONE && (fd_[ps] || E.nulcut), E.p10,
+                                        flen, elo, ehi, value, valid);
+            plain = __builtin_amdgcn_ballot_w64(!sc) == 0 && (typed == tyu || typed == T_NONE);
+            if (plain) {
+                fast = true;
+                if (!act) {
+                    flen = 0;
+                    valid = false;
+                }
+            } else {
+                flen = 0;
+                elo = ehi = value = 0;
+                valid = false;
+            }
+        }
+        if (!plain && r < RBn) {
             const uint32_t s = cs_[ps], len = cl_[ps], lvl = cv_[ps];
             const bool found = fd_[ps];
             const bool convert = typed != T_NONE && (found || E.nulcut);
@@ -871,8 +977,7 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
 #ifdef MDC_ABLATE
             if (E.dbg & 64) ty = T_NONE;
 #endif
-            uint64_t value = 0;
-            bool valid = false, later = false;
+            bool later = false;
             if (len <= 16) {
                 const uint4 w4 = lds_u128(sdata + s);
                 const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
@@ -892,7 +997,10 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
                 flen = cell_filter_long<false>(sdata + s, len, lvl, E.nulcut, nullptr);
                 if (ty != T_NONE) deferred = true;  // value and valid bit come from the second stage
             }
-            if (WRITE && convert && valid) atomicOr(&E.vmask[r * E.W + (c >> 5)], 1u << (c & 31));
+            valid = valid && convert;
+        }
+        if (r < RBn) {
+            if (WRITE && valid) atomicOr(&E.vmask[r * E.W + (c >> 5)], 1u << (c & 31));
 #ifdef MDC_ABLATE
             if (valp && !(E.dbg & 512)) valp[rowbase + r] = value;
 #else
@@ -1443,6 +1551,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         E.vmask = vmask;
         E.wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
         E.wstage_cap = L.stage_cap / (BLOCK / 64);
+        E.plain_ok = !(nulcut && has_nul);
         const uint32_t slot = map_slot;
         const bool mapping = !WRITE && slot != NONE;
         // the source of cell (c, r): start, length, filter level, found
@@ -1542,7 +1651,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             }
         } else
         for (uint32_t c = wave; c < ncols && !SKIP(2); c += BLOCK / 64) {
-            const uint32_t typed = cols[c].typed;
+            const uint32_t typed = (uint32_t)__builtin_amdgcn_readfirstlane((int)cols[c].typed);
             uint32_t cs_[RB_PASSES], cl_[RB_PASSES], cv_[RB_PASSES];
             bool fd_[RB_PASSES];
 #pragma unroll
@@ -1758,6 +1867,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     E.vmask = vmask;
     E.wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
     E.wstage_cap = L.stage_cap / (BLOCK / 64);
+    E.plain_ok = !(E.nulcut && has_nul);
     E.nostore = SKIP(32);
 #ifdef MDC_ABLATE
     E.dbg = P.debug;
@@ -1788,7 +1898,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             const ColOut O = colout[c];
             const uint64_t gb = O.base + tiletot[c];
             const uint32_t total =
+#ifdef MDC_EXP_A
+                column_cells<true>(E, O, c, (uint32_t)__builtin_amdgcn_readfirstlane((int)cols[c].typed), lane, RBn,
+                                   row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);  // (the type in a scalar register: its branches are the wave's)
+#else
                 column_cells<true>(E, O, c, cols[c].typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
+#endif
             if (lane == 0) tiletot[c] += total;  // this wave owns column c
         }
         __syncthreads();
