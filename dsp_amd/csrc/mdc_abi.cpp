@@ -174,7 +174,9 @@ struct mdc_parser {
     uint32_t *d_counts = nullptr;
     uint64_t *d_base = nullptr;
     uint32_t *d_status = nullptr;
-    uint32_t *d_tmpl = nullptr;     // tag template of the current input (see TMPL_MAX)
+    uint32_t *d_tmpl = nullptr;     // tag template (see TMPL_MAX): built from the first input, kept while the
+    bool tmpl_valid = false;        // inputs follow it (any template of this schema gives right results: a tile
+                                    // whose records differ takes the table lookup), rebuilt when many tiles do not
     uint32_t *d_hdr = nullptr;      // per tile: cell map slot, first record start
     uint32_t *d_cellmap = nullptr;  // (ncols + 1) x map_cap words
     size_t map_cap = 0, map_stride = 0;
@@ -680,16 +682,24 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     // with the next larger capacity (which costs blocks per CU, so it is not the default).
     for (;;) {
         P.L = p->LSs[p->lb_level];
-        HIP_TRY(hipMemsetAsync(p->d_status, 0, 4, s));
+        HIP_TRY(hipMemsetAsync(p->d_status, 0, 8, s));  // status word, tiles that left the template
         HIP_TRY(hipEventRecord(p->ev[0], s));
-        HIP_TRY(launch_template_kernel(P, s));
+        const bool build_tmpl = P.use_tmpl && !p->tmpl_valid && ntiles;
+        if (build_tmpl) HIP_TRY(launch_template_kernel(P, s));
         HIP_TRY(launch_tile_kernel(false, P, s));
         HIP_TRY(hipEventRecord(p->ev[1], s));
         HIP_TRY(launch_scan_tiles(p->d_counts, p->d_base, (uint32_t)ntiles, ncnt, s));
         HIP_TRY(hipEventRecord(p->ev[2], s));
         HIP_TRY(hipMemcpyAsync(p->h_totals, p->d_base + ntiles * ncnt, ncnt * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(p->h_totals + ncnt, p->d_status, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(p->h_totals + ncnt, p->d_status, 8, hipMemcpyDeviceToHost, s));
+        if (build_tmpl) HIP_TRY(hipMemcpyAsync(p->h_totals + ncnt + 1, p->d_tmpl, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (P.use_tmpl && ntiles) {
+            // keep a template that exists and that most tiles followed
+            const uint64_t left = p->h_totals[ncnt] >> 32;
+            if (build_tmpl) p->tmpl_valid = (uint32_t)p->h_totals[ncnt + 1] != 0;
+            if (left * 8 > ntiles) p->tmpl_valid = false;
+        }
         if (((uint32_t)p->h_totals[ncnt] & ST_RECORD_TOO_LONG) && p->lb_level < 2) {
             ++p->lb_level;
             continue;

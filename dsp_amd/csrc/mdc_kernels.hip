@@ -392,7 +392,27 @@ __global__ __launch_bounds__(64) void template_kernel(const TileParams P) {
     uint8_t *win = smem + sb;
     for (uint32_t i = lane; i < P.schema_bytes / 16; i += 64) ((uint4 *)smem)[i] = ((const uint4 *)P.schema)[i];
     const uint32_t nwin = P.n < TMPL_WINDOW ? (uint32_t)P.n : TMPL_WINDOW;
-    for (uint32_t i = lane; i < TMPL_WINDOW + 64; i += 64) win[i] = i < nwin ? P.data[i] : 0;
+    constexpr uint32_t WCH = (TMPL_WINDOW + 64) / 16;  // 16-byte chunks of the window; zeros behind the input
+    if (P.n >= TMPL_WINDOW + 64) {                     // (all loads in flight at once)
+        uint4 tv[(WCH + 63) / 64];
+#pragma unroll
+        for (uint32_t k = 0; k < (WCH + 63) / 64; ++k) {
+            const uint32_t i = k * 64 + lane;
+            tv[k] = ((const uint4 *)P.data)[i < WCH ? i : 0];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < (WCH + 63) / 64; ++k) {
+            const uint32_t i = k * 64 + lane;
+            if (i < WCH) ((uint4 *)win)[i] = tv[k];
+        }
+    } else {
+        for (uint32_t i = lane; i < WCH; i += 64) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (uint32_t k = 0; k < 16; ++k)
+                if ((uint64_t)i * 16 + k < P.n) w[k >> 2] |= (uint32_t)P.data[(uint64_t)i * 16 + k] << (8 * (k & 3));
+            ((uint4 *)win)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
     if (lane < 2) tpos[lane] = -1;
     if (lane < 2 * MAX_COLS / 32) seen[lane] = 0;
     if (lane == 0) bad = 0;
@@ -402,12 +422,20 @@ __global__ __launch_bounds__(64) void template_kernel(const TileParams P) {
     const HtEntry *ht = (const HtEntry *)((const uint8_t *)cols + ((H->ncols * sizeof(DevCol) + 15) & ~15u));
     const int el = (int)H->endbz_len;
     uint64_t tm = 0, em = 0;
-    for (int b = 0; b < 64; ++b) {
-        const int p = lane * 64 + b;
-        if (p >= (int)nwin) break;
-        const uint8_t c = win[p];
-        if (c == '<') em |= 1ull << b;
-        if (c == '\n') {
+    {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ((const uint4 *)win)[lane * 4 + k];
+        uint64_t nlm = mask64_eq(v, 0x0A0A0A0Au);
+        em = mask64_eq(v, 0x3C3C3C3Cu);
+        const int lim = (int)nwin - lane * 64;  // bytes of this lane that belong to the window
+        const uint64_t keep = lim >= 64 ? ~0ull : lim <= 0 ? 0ull : (~0ull >> (64 - lim));
+        nlm &= keep;
+        em &= keep;
+        while (nlm) {
+            const int b = __builtin_ctzll(nlm);
+            nlm &= nlm - 1;
+            const int p = lane * 64 + b;
             bool t = p - el >= 0;
             for (int k = 0; t && k < el; ++k) t = win[p - el + k] == H->endbz[k];
             if (t) tm |= 1ull << b;
@@ -1696,6 +1724,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     }
 
     if (!WRITE) {
+        if (tmode && irregular && tid == 0) atomicAdd(P.status + 1, 1u);  // the host renews a template few tiles follow
         uint32_t *tc = P.tile_counts + (uint64_t)blockIdx.x * (ncols + 1);
         for (uint32_t c = tid; c < ncols; c += BLOCK) tc[c] = tiletot[c];
         if (tid == 0) {

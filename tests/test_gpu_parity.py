@@ -247,6 +247,27 @@ def test_workspace_follows_the_input_shape(port):
     p.close()
 
 
+def test_tag_template_follows_the_input(port):
+    """One parser, inputs whose records have different tag sequences, one after the other: the
+    sizing pass keeps the template of an earlier input while tiles follow it, sends the tiles of a
+    different input through the table lookup and renews the template on the parse after that."""
+    import re
+    a, _ = gen.mind_xml(rows=40000)
+    a = a.tobytes()
+    b = re.sub(rb"(<t>[^<]*</t>)(<p>[^<]*</p>)", rb"\2\1", a)           # two tags the other way round
+    c = re.sub(rb"<wd>", rb"<x>1</x><wd>", a)                              # a tag the schema does not know
+    d = re.sub(rb"(<u>[^<]*</u>)", rb"\1\1", a)                           # a tag twice
+    e = b"".join((x + b"\n") if i % 7 else (x.replace(b"</r>", b"</r><r>9</r>") + b"\n")
+                 for i, x in enumerate(a.split(b"\n")[:-1])) + a.split(b"\n")[-1]  # some records differ
+    tiny = b"<obtid>58015</obtid><endl/>\n"                                 # no second record: no template
+    p = capi.Parser.xml(schema.ZHOBTMIND)
+    for name, data in (("a", a), ("b", b), ("b again", b), ("a again", a), ("c", c), ("c again", c), ("d", d),
+                       ("tiny", tiny), ("e", e), ("e again", e), ("a at the end", a)):
+        got = p.parse_host(data).to_host()
+        assert_batches_equal(got, port.parse_xml(data, schema.ZHOBTMIND), name)
+    p.close()
+
+
 def test_many_tiles(port):
     data, n = gen.mind_xml(nbytes=48 << 20)
     p = capi.Parser.xml(schema.ZHOBTMIND)
