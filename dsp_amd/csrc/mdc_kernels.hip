@@ -193,6 +193,41 @@ __device__ __forceinline__ uint4 lds_u128(const uint8_t *p) {
     return v;
 }
 
+// The same bytes through aligned dword reads.  An LDS access that is not aligned to its own size
+// is taken lane by lane (measured: 66 cycles of the LDS pipe per wave instruction against 7-8
+// for an aligned one), so a window at an arbitrary address is read as the aligned dwords around
+// it (ds_read2_b32: two dwords, 4-byte alignment is enough) and shifted into place with
+// v_alignbyte.  The reads are written out because the compiler would merge dword loads of a
+// pointer into one wide, misaligned access.
+typedef uint32_t lds_u32x2 __attribute__((ext_vector_type(2)));
+// bytes [p, p + 12)
+__device__ __forceinline__ void lds_bytes12(const uint8_t *p, uint32_t &w0, uint32_t &w1, uint32_t &w2) {
+    const uint32_t addr = (uint32_t)(size_t)p;  // (the low half of a pointer into LDS is the LDS address)
+    const uint32_t base = addr & ~3u, sh = addr & 3u;
+    lds_u32x2 a, b;
+    asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read2_b32 %1, %2 offset0:2 offset1:3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(base)
+                 : "memory");
+    w0 = __builtin_amdgcn_alignbyte(a[1], a[0], sh);
+    w1 = __builtin_amdgcn_alignbyte(b[0], a[1], sh);
+    w2 = __builtin_amdgcn_alignbyte(b[1], b[0], sh);
+}
+// bytes [p, p + 16)
+__device__ __forceinline__ uint4 lds_bytes16(const uint8_t *p) {
+    const uint32_t addr = (uint32_t)(size_t)p;
+    const uint32_t base = addr & ~3u, sh = addr & 3u;
+    lds_u32x2 a, b;
+    uint32_t c;
+    asm volatile("ds_read2_b32 %0, %3 offset1:1\n\tds_read2_b32 %1, %3 offset0:2 offset1:3\n\tds_read_b32 %2, %3 offset:16\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c)
+                 : "v"(base)
+                 : "memory");
+    return make_uint4(__builtin_amdgcn_alignbyte(a[1], a[0], sh), __builtin_amdgcn_alignbyte(b[0], a[1], sh),
+                      __builtin_amdgcn_alignbyte(b[1], b[0], sh), __builtin_amdgcn_alignbyte(c, b[1], sh));
+}
+
 // 64-bit byte-equality mask of the 64 bytes held in four dwordx4 registers
 __device__ __forceinline__ uint64_t mask64_eq(const uint4 (&v)[4], uint32_t pat4) {
     const uint32_t lo = pack32(bytes_eq7(v[0].x, pat4), bytes_eq7(v[0].y, pat4), bytes_eq7(v[0].z, pat4),
@@ -365,9 +400,9 @@ __device__ __forceinline__ bool tmpl_event(const uint8_t *sdata, const uint4 *tl
                                            uint32_t *evt, uint32_t rl, uint32_t RB) {
     if (k >= nT) return false;
     const uint4 t = tl[k];
-    const uint64_t w = lds_u64(sdata + q + 1);
-    uint32_t w2;
-    __builtin_memcpy(&w2, sdata + q + 9, 4);
+    uint32_t w0, w1, w2;
+    lds_bytes12(sdata + q + 1, w0, w1, w2);
+    const uint64_t w = (uint64_t)w0 | ((uint64_t)w1 << 32);
     const uint32_t L = t.w & 0xFFu, idx = t.w >> 8;  // 1 <= L <= TMPL_MAXLEN
     const uint32_t n1 = L < 8 ? L : 8;
     const uint64_t m1 = ~0ull >> (64 - 8 * n1);
