@@ -465,10 +465,10 @@ static int parser_finish(mdc_parser *p, const mdc_opts *opts) {
     if (rc) return rc;
     p->d_status = (uint32_t *)st;
     HIP_TRY(hipMemset(p->d_status, 0, 256));
-    rc = dev_alloc(p->dev, (1 + TMPL_MAX) * 16, &st);
+    rc = dev_alloc(p->dev, (1 + TMPL_MAX) * 16 + MAX_COLS * 8 + 16, &st);
     if (rc) return rc;
     p->d_tmpl = (uint32_t *)st;
-    HIP_TRY(hipMemset(p->d_tmpl, 0, (1 + TMPL_MAX) * 16));
+    HIP_TRY(hipMemset(p->d_tmpl, 0, (1 + TMPL_MAX) * 16 + MAX_COLS * 8 + 16));
     HIP_TRY(hipHostMalloc((void **)&p->h_totals, (MAX_COLS + 8) * sizeof(uint64_t), hipHostMallocDefault));
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&p->ev[i]));
     return MDC_OK;

@@ -27,7 +27,12 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 // number of events, 0 = no template), then one 4-word entry per event: the first 8 bytes of the
 // tag text through '>' (zero beyond it), bytes 8..11, and length | pattern index << 8
 // (TMPL_NOPAT: the sample's event matched no pattern).
+// Behind the TMPL_MAX entries: the column plan, two words per column, for records that follow the
+// template: source column of the cell (itself, or the nearest earlier column whose tags the sample
+// has, when values carry over) | filter level << 8 | found << 10 | has a source << 11 |
+// (name length + 2) << 16, and the source column's clip length.
 constexpr uint32_t TMPL_MAX = 64;
+constexpr uint32_t TMPL_PLAN_WORD = 4 + 4 * 64;  // word index of the plan (= 4 + 4 * TMPL_MAX)
 constexpr uint32_t TMPL_MAXLEN = 12;
 constexpr uint32_t TMPL_NOPAT = 0xFFFFFFu;
 constexpr uint32_t TMPL_WINDOW = 4096;  // the sample record is the second record of the input and must end in this window

@@ -546,6 +546,27 @@ __global__ __launch_bounds__(64) void template_kernel(const TileParams P) {
         ++k;
     }
     __syncthreads();
+    // the column plan: what splitbuffer's column loop does for a record with the sample's tags
+    for (uint32_t c = lane; c < H->ncols; c += 64) {
+        auto has = [&](uint32_t col) {
+            return ((seen[(2 * col) >> 5] >> ((2 * col) & 31)) & 1u) && ((seen[(2 * col + 1) >> 5] >> ((2 * col + 1) & 31)) & 1u);
+        };
+        const bool found = has(c);
+        uint32_t cs = c, lvl = cols[c].level;
+        bool have = found;
+        if (!found && H->carry)
+            while (cs > 0) {
+                --cs;
+                if (cols[cs].level > lvl) lvl = cols[cs].level;
+                if (has(cs)) {
+                    have = true;
+                    break;
+                }
+            }
+        P.tmpl[TMPL_PLAN_WORD + 2 * c] = cs | (lvl << 8) | ((uint32_t)found << 10) | ((uint32_t)have << 11) |
+                                         (((uint32_t)cols[cs].namelen + 2) << 16);
+        P.tmpl[TMPL_PLAN_WORD + 2 * c + 1] = (uint32_t)cols[cs].collen;
+    }
     if (lane == 0) P.tmpl[0] = bad ? 0 : nT;
 }
 
@@ -1179,8 +1200,11 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     // tile's first record that lie in the look-behind), then the template's entries
     int16_t *e0t = (int16_t *)(smem + L.vmask);
     const uint32_t e0_bytes = ((L.RB + 2) * 2 + 15) & ~15u;
-    uint4 *tmpl_l = (uint4 *)(smem + L.vmask + e0_bytes);
-    const uint32_t tmpl_room = L.coltot - L.vmask > e0_bytes ? (L.coltot - L.vmask - e0_bytes) / 16 : 0;
+    const uint32_t plan_bytes = (P.ncols * 8 + 15) & ~15u;
+    uint2 *plan_l = (uint2 *)(smem + L.vmask + e0_bytes);  // the template's column plan
+    uint4 *tmpl_l = (uint4 *)(smem + L.vmask + e0_bytes + plan_bytes);
+    const uint32_t tmpl_room =
+        L.coltot - L.vmask > e0_bytes + plan_bytes ? (L.coltot - L.vmask - e0_bytes - plan_bytes) / 16 : 0;
     const uint32_t tmpl_cap = tmpl_room < TMPL_MAX ? tmpl_room : TMPL_MAX;
     const uint32_t nT_in = P.tmpl[0];
 
@@ -1217,12 +1241,15 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         const uint4 sv = g[(uint32_t)tid < sch16 ? tid : 0];
         // tag template (sizing pass of tagged input): entry k sits behind the event-index array
         // in the space of the two row masks, which that pass does not use
-        const uint4 tq = ((const uint4 *)P.tmpl)[(uint32_t)tid <= TMPL_MAX ? tid : 0];
+        const uint32_t plan16 = (P.ncols + 1) / 2;  // 16-byte pieces of the plan, behind the entries
+        const uint4 tq = ((const uint4 *)P.tmpl)[(uint32_t)tid <= TMPL_MAX + plan16 ? tid : 0];
 #pragma unroll
         for (int k = 0; k < 4; ++k) ((uint4 *)sdata)[ts_li / CHUNK + k * BLOCK + tid] = tv[k];
         if (lbmine) ((uint4 *)sdata)[jlb] = lbv;
         if ((uint32_t)tid < sch16) s[tid] = sv;
         if (!WRITE && P.use_tmpl && tid >= 1 && (uint32_t)tid <= tmpl_cap) tmpl_l[tid - 1] = tq;
+        if (!WRITE && P.use_tmpl && tmpl_room && (uint32_t)tid > TMPL_MAX && (uint32_t)tid <= TMPL_MAX + plan16)
+            ((uint4 *)plan_l)[tid - 1 - TMPL_MAX] = tq;
         for (uint32_t i = tid + BLOCK; i < sch16; i += BLOCK) s[i] = g[i];
         if (tid < MS_COUNT) ms[tid] = tid == MS_LAST ? NONE : 0;
     }
@@ -1679,7 +1706,25 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 if (act) {
                     uint32_t s, len, lvl;
                     bool found;
-                    fetch_cell(c, r, s, len, lvl, found);
+                    if (tmode && !irregular) {
+                        // every record of the tile has the sample's tags: which column a cell comes
+                        // from, its level and the clip are the plan's, only the positions are the record's
+                        const uint2 pl = plan_l[c];
+                        const uint32_t cs = pl.x & 0xFFu, nml2 = pl.x >> 16;
+                        const int cl = (int)pl.y;
+                        lvl = (pl.x >> 8) & 3u;
+                        found = (pl.x >> 10) & 1u;
+                        const uint32_t o = ((const uint16_t *)evt)[(2 * cs) * RB + r], e = ((const uint16_t *)evt)[(2 * cs + 1) * RB + r];
+                        const uint32_t re = recend[r + 1];
+                        s = o + nml2;
+                        int l = (int)e - (int)s;
+                        l = l < 0 ? (int)(re - s) : (cl > 0 && cl < l) ? cl : l;
+                        const bool have = (pl.x >> 11) & 1u;
+                        s = have ? s : 0u;
+                        len = have ? (uint32_t)l : 0u;
+                    } else {
+                        fetch_cell(c, r, s, len, lvl, found);
+                    }
                     if (mapping) {
                         if (len < MAP_MAXLEN)
                             P.cellmap[(uint64_t)c * P.map_cap + slot + rb0 + r] = map_pack(s, len, lvl, found);
@@ -1687,19 +1732,19 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                             ms[MS_NOMAP] = 1;
                     }
                     if (len <= 16) {
-                        const uint4 w4 = lds_u128(sdata + s);
-                        const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
-                        const uint64_t hi = (uint64_t)w4.z | ((uint64_t)w4.w << 32);
                         const bool cutting = lvl == LVL_CHAR && nulcut && has_nul;
-                        uint64_t value, elo, ehi;
-                        bool valid, later = false, fast = false;
                         if (lvl == LVL_CHAR && !cutting) {
-                            flen = len;
-                            fast = true;
-                        } else if (!cutting) {
-                            fast = cell_fast(lo, hi, len, digit_mask16(w4), lvl, T_NONE, p10, flen, value, valid, elo, ehi, later);
+                            flen = len;  // (a text cell is not looked at)
+                        } else {
+                            const uint4 w4 = lds_bytes16(sdata + s);
+                            const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
+                            const uint64_t hi = (uint64_t)w4.z | ((uint64_t)w4.w << 32);
+                            uint64_t value, elo, ehi;
+                            bool valid, later = false, fast = false;
+                            if (!cutting)
+                                fast = cell_fast(lo, hi, len, digit_mask16(w4), lvl, T_NONE, p10, flen, value, valid, elo, ehi, later);
+                            if (!fast) flen = cell_scan16<false>(lo, hi, len, lvl, nulcut, T_NONE, p10, nullptr, value, valid, later);
                         }
-                        if (!fast) flen = cell_scan16<false>(lo, hi, len, lvl, nulcut, T_NONE, p10, nullptr, value, valid, later);
                     } else {
                         flen = cell_filter_long<false>(sdata + s, len, lvl, nulcut, nullptr);
                     }

@@ -25,7 +25,13 @@ d = capi.DeviceBuffer(data) if src == "device" else None
 best = None
 for i in range(parses):
     t0 = time.perf_counter()
-    b = p.parse_device(d.ptr, d.n) if d else p.parse_host(data)
+    try:
+        b = p.parse_device(d.ptr, d.n) if d else p.parse_host(data)
+    except capi.MdcError as e:  # (ablated diagnostic builds leave inconsistent outputs)
+        if not os.environ.get("MDC_DEBUG_SKIP"):
+            raise
+        print("  parse error expected in ablation:", e.code)
+        continue
     wall = time.perf_counter() - t0
     t = p.timing()
     print(f"{wl}/{src} parse {i}: count {t.count_ms:.3f} scan {t.scan_ms:.3f} write {t.write_ms:.3f} "
