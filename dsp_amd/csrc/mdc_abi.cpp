@@ -673,6 +673,8 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     P.use_tmpl = p->mode == MODE_XML ? 1u : 0u;
 #ifdef MDC_ABLATE
     if (getenv("MDC_NO_TEMPLATE")) P.use_tmpl = 0;
+    if (const char *dbg = getenv("MDC_DEBUG_SKIP"))
+        if (atoi(dbg) & 1) P.use_tmpl = 0;  // (no tag search: nothing would follow the template)
     if (const char *dbg = getenv("MDC_DEBUG_SKIP")) P.debug = (uint32_t)atoi(dbg);
 #endif
 

@@ -1703,7 +1703,42 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 const uint32_t c = !act ? ncols - 1 : RBn == 1 ? i : __umulhi(i, magic);
                 const uint32_t r = act ? i - c * RBn : 0;
                 uint32_t flen = 0;
-                if (act) {
+                bool measured = false;
+                if (tmode && !irregular && !(nulcut && has_nul)) {
+                    // A tile that follows the template, a whole wave of short cells at once and
+                    // without a per-lane branch: source from the column plan, 16 bytes of it, digit
+                    // mask.  The date level keeps the digits, text keeps everything, and so does a
+                    // number that has only a sign in front and one point besides its digits.
+                    const uint2 pl = plan_l[c];
+                    const uint32_t cs = pl.x & 0xFFu, nml2 = pl.x >> 16;
+                    const int cl = (int)pl.y;
+                    const uint32_t lvl = (pl.x >> 8) & 3u;
+                    const uint32_t o = ((const uint16_t *)evt)[(2 * cs) * RB + r], e = ((const uint16_t *)evt)[(2 * cs + 1) * RB + r];
+                    const uint32_t re = recend[r + 1];
+                    // (a source column's tags are there in every record that follows the template;
+                    // the test on the positions only keeps a length in bounds whatever happens)
+                    const bool have = ((pl.x >> 11) & 1u) & act & (o != NONE16) & (e != NONE16);
+                    const uint32_t s1 = o + nml2;
+                    int l = (int)e - (int)s1;
+                    l = l < 0 ? (int)(re - s1) : (cl > 0 && cl < l) ? cl : l;
+                    const uint32_t s = have ? s1 : 0u, len = have ? (uint32_t)l : 0u;
+                    const uint4 w4 = lds_bytes16(sdata + s);
+                    const uint32_t D16 = digit_mask16(w4);
+                    const uint32_t Lm = (1u << (len < 16 ? len : 16)) - 1;
+                    const uint32_t N = ~D16 & Lm;
+                    const uint32_t c0 = w4.x & 0xFFu;
+                    const uint32_t N1 = N & ~(uint32_t)((c0 == '+') | (c0 == '-'));
+                    const uint32_t pp = (uint32_t)__builtin_ctz(N1 | 0x10000u) & 15u;
+                    const uint32_t wp = pp < 4 ? w4.x : pp < 8 ? w4.y : pp < 12 ? w4.z : w4.w;
+                    const bool numplain = ((N1 & (N1 - 1)) == 0) & ((N1 == 0) | (((wp >> (8 * (pp & 3))) & 0xFFu) == '.'));
+                    const bool ok = (len <= 16) & ((lvl != LVL_NUMBER) | numplain);
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+                        measured = true;
+                        flen = lvl == LVL_DATE ? (uint32_t)__builtin_popcount(D16 & Lm) : len;
+                        if (mapping && act) P.cellmap[(uint64_t)c * P.map_cap + slot + rb0 + r] = map_pack(s, len, lvl, (pl.x >> 10) & 1u);
+                    }
+                }
+                if (act && !measured) {
                     uint32_t s, len, lvl;
                     bool found;
                     if (tmode && !irregular) {
@@ -1719,7 +1754,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                         s = o + nml2;
                         int l = (int)e - (int)s;
                         l = l < 0 ? (int)(re - s) : (cl > 0 && cl < l) ? cl : l;
-                        const bool have = (pl.x >> 11) & 1u;
+                        const bool have = ((pl.x >> 11) & 1u) & (o != NONE16) & (e != NONE16);
                         s = have ? s : 0u;
                         len = have ? (uint32_t)l : 0u;
                     } else {
@@ -1741,8 +1776,23 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                             const uint64_t hi = (uint64_t)w4.z | ((uint64_t)w4.w << 32);
                             uint64_t value, elo, ehi;
                             bool valid, later = false, fast = false;
-                            if (!cutting)
-                                fast = cell_fast(lo, hi, len, digit_mask16(w4), lvl, T_NONE, p10, flen, value, valid, elo, ehi, later);
+                            // the length alone: the date level keeps the digits; a number that has
+                            // only a sign in front and one point besides its digits keeps everything
+                            const uint32_t D16 = digit_mask16(w4);
+                            const uint32_t Lm = (1u << len) - 1;
+                            const uint32_t N = ~D16 & Lm;
+                            const uint32_t c0 = w4.x & 0xFFu;
+                            const uint32_t N1 = N & ~(uint32_t)((c0 == '+') | (c0 == '-'));
+                            const uint32_t pp = (uint32_t)__builtin_ctz(N1 | 0x10000u);
+                            if (lvl == LVL_DATE) {
+                                flen = (uint32_t)__builtin_popcount(D16 & Lm);
+                                fast = true;
+                            } else if (lvl == LVL_NUMBER && (N1 & (N1 - 1)) == 0 && (N1 == 0 || win_byte(lo, hi, pp & 15) == '.')) {
+                                flen = len;
+                                fast = true;
+                            } else if (!cutting) {
+                                fast = cell_fast(lo, hi, len, D16, lvl, T_NONE, p10, flen, value, valid, elo, ehi, later);
+                            }
                             if (!fast) flen = cell_scan16<false>(lo, hi, len, lvl, nulcut, T_NONE, p10, nullptr, value, valid, later);
                         }
                     } else {
