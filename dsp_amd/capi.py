@@ -67,6 +67,7 @@ class COpts(ctypes.Structure):
         ("carry", ctypes.c_int),
         ("typed", ctypes.POINTER(ctypes.c_int)),
         ("flags", ctypes.c_uint),
+        ("tz_offset", ctypes.c_int),
     ]
 
 
@@ -288,11 +289,11 @@ class Parser:
 
     @classmethod
     def xml(cls, cols: Sequence[Col], typed: Optional[Sequence[int]] = None, endbz: Optional[str] = "<endl/>",
-            carry: bool = True, device: int = 0, flags: int = 0) -> "Parser":
+            carry: bool = True, device: int = 0, flags: int = 0, tz_offset: int = 0) -> "Parser":
         cc = c_cols(cols)
         ty = (ctypes.c_int * len(cols))(*typed) if typed is not None else None
         opts = COpts(device, endbz.encode() if endbz is not None else None, int(carry),
-                     ctypes.cast(ty, ctypes.POINTER(ctypes.c_int)) if ty is not None else None, flags)
+                     ctypes.cast(ty, ctypes.POINTER(ctypes.c_int)) if ty is not None else None, flags, tz_offset)
         h = ctypes.c_void_p()
         check(lib().mdc_parser_create_xml(cc, len(cols), ctypes.byref(opts), ctypes.byref(h)))
         return cls(h, device, (cc, ty, opts))
@@ -300,10 +301,11 @@ class Parser:
     @classmethod
     def csv(cls, sep: str, nfields: int, ilen: Optional[Sequence[int]] = None,
             typed: Optional[Sequence[int]] = None, bdelspace: bool = False, device: int = 0,
-            flags: int = 0) -> "Parser":
+            flags: int = 0, tz_offset: int = 0) -> "Parser":
         il = (ctypes.c_int * nfields)(*ilen) if ilen is not None else None
         ty = (ctypes.c_int * nfields)(*typed) if typed is not None else None
-        opts = COpts(device, None, 0, ctypes.cast(ty, ctypes.POINTER(ctypes.c_int)) if ty is not None else None, flags)
+        opts = COpts(device, None, 0, ctypes.cast(ty, ctypes.POINTER(ctypes.c_int)) if ty is not None else None, flags,
+                     tz_offset)
         h = ctypes.c_void_p()
         check(lib().mdc_parser_create_csv(sep.encode(), int(bdelspace), nfields,
                                           ctypes.cast(il, ctypes.POINTER(ctypes.c_int)) if il is not None else None,

@@ -295,7 +295,7 @@ static void compute_emit_layout(uint32_t ncols, uint32_t words, uint32_t lbmax, 
 // look-behind capacities tried in turn when a record does not fit (fewer blocks per CU each)
 static const uint32_t LB_LEVELS[3] = {1536, 8192, LBMAX};
 
-static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *sep, int bdelspace) {
+static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *sep, int bdelspace, int tz_offset) {
     const uint32_t ncols = (uint32_t)p->ncols;
     const uint32_t npat = p->mode == MODE_XML ? 2 * ncols : 0;
     size_t el = strlen(endbz);
@@ -326,7 +326,7 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
             dc[c].level = LVL_CHAR;  // splitbuffer leaves every other type untouched
         int t = p->typed[c];
         if (t == MDC_T_DEFAULT) t = dc[c].level == LVL_NUMBER ? MDC_T_F64 : dc[c].level == LVL_DATE ? MDC_T_I64 : MDC_T_NONE;
-        if (t < MDC_T_NONE || t > MDC_T_BOOL) return fail(MDC_ERR_ARG, "column %u: bad typed code %d", c, t);
+        if (t < MDC_T_NONE || t > MDC_T_TIME) return fail(MDC_ERR_ARG, "column %u: bad typed code %d", c, t);
         p->typed[c] = t;
         dc[c].typed = (uint8_t)t;
         if (t != MDC_T_NONE) any_typed = 1;
@@ -431,6 +431,7 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
     H->words = p->words;
     H->bdelspace = bdelspace ? 1 : 0;
     H->any_typed = any_typed;
+    H->tz_offset = tz_offset;
     H->endbz_len = (uint32_t)el;
     memcpy(H->endbz, endbz, el);
     if (el <= 8) memcpy(H->endbz_tail + 8 - el, endbz, el);
@@ -488,7 +489,7 @@ extern "C" int mdc_parser_create_xml(const mdc_col *cols, int ncols, const mdc_o
     if (opts && opts->typed) p->typed.assign(opts->typed, opts->typed + ncols);
     const char *endbz = (opts && opts->endbz) ? opts->endbz : "<endl/>";
     int carry = opts ? opts->carry : 1;
-    int rc = build_blob(p, endbz, carry, "", 0);
+    int rc = build_blob(p, endbz, carry, "", 0, opts ? opts->tz_offset : 0);
     if (!rc) rc = parser_finish(p, opts);
     if (rc) {
         mdc_parser_destroy(p);
@@ -520,7 +521,7 @@ extern "C" int mdc_parser_create_csv(const char *sep, int bdelspace, int nfields
     for (int c = 0; c < nfields; ++c)
         if (p->typed[c] == MDC_T_DEFAULT) p->typed[c] = MDC_T_NONE;
     const char *endbz = (opts && opts->endbz) ? opts->endbz : "";
-    int rc = build_blob(p, endbz, 0, sep, bdelspace);
+    int rc = build_blob(p, endbz, 0, sep, bdelspace, opts ? opts->tz_offset : 0);
     if (!rc) rc = parser_finish(p, opts);
     if (rc) {
         mdc_parser_destroy(p);

@@ -1031,7 +1031,7 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
         // a whole pass of plain cells takes the straight-line path
         bool plain = false;
         if (WRITE && E.plain_ok) {
-            uint32_t tyu = (typed == T_F32 || typed == T_BOOL) ? (uint32_t)T_NONE : typed;
+            uint32_t tyu = (typed == T_F32 || typed == T_BOOL || typed == T_TIME) ? (uint32_t)T_NONE : typed;
 #ifdef MDC_ABLATE
             if (E.dbg & 64) tyu = T_NONE;
 #endif
@@ -1062,6 +1062,10 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
             if (E.dbg & 64) ty = T_NONE;
 #endif
             bool later = false;
+            if (ty == T_TIME) {  // calendar arithmetic is the second stage's: here the cell is text
+                ty = T_NONE;
+                deferred = true;
+            }
             if (len <= 16) {
                 const uint4 w4 = lds_u128(sdata + s);
                 const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
@@ -2183,8 +2187,12 @@ __global__ __launch_bounds__(256) void deferred_convert_kernel(const uint8_t *sc
         const uint32_t o = off[c][r], len = off[c][r + 1] - o;
         uint64_t v = 0;
         bool ok = false, range = false;
-        cell_walk<false>(bytes[c] + o, len, LVL_CHAR, false, typed, nullptr, v, ok, range);
-        if (range) ok = big_convert(bytes[c] + o, len, typed == T_F64, v);
+        if (typed == T_TIME) {
+            ok = time_convert(bytes[c] + o, len, H->tz_offset, v);
+        } else {
+            cell_walk<false>(bytes[c] + o, len, LVL_CHAR, false, typed, nullptr, v, ok, range);
+            if (range) ok = big_convert(bytes[c] + o, len, typed == T_F64, v);
+        }
         if (ok) {
             val[c][r] = v;
             atomicOr(&valid[r * W + (c >> 5)], bit);

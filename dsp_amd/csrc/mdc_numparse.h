@@ -20,7 +20,46 @@
 namespace mdc {
 
 // values of MDC_T_* (include/mdc_parse.h)
-enum : uint8_t { T_NONE = 0, T_I32 = 1, T_U32 = 2, T_I64 = 3, T_U64 = 4, T_F64 = 5, T_F32 = 6, T_BOOL = 7 };
+enum : uint8_t { T_NONE = 0, T_I32 = 1, T_U32 = 2, T_I64 = 3, T_U64 = 4, T_F64 = 5, T_F32 = 6, T_BOOL = 7, T_TIME = 8 };
+
+// strtotime (reference public/_public.cpp:1009-1044): the digits of the text must be exactly
+// fourteen, yyyymmddhh24miss; the fields go to mktime as they are (month - 1, isdst 0), and mktime
+// takes fields out of their ranges arithmetically (month 00 is December of the year before, day
+// 00 the last day of the month before, hour 99 four days on).  For a zone without daylight saving
+// that is plain calendar arithmetic minus the zone's offset (glibc __mktime_internal: year and
+// month folded, days before the month by leap-year table, ydhms difference to 1970).
+// tz_offset = seconds east of UTC.  false when the text does not hold fourteen digits.
+__device__ inline bool time_convert(const uint8_t *s, uint32_t n, int32_t tz_offset, uint64_t &value) {
+    uint32_t d[14], nd = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t c = (uint32_t)s[i] - '0';
+        if (c < 10u) {
+            if (nd < 14) d[nd] = c;
+            ++nd;
+        }
+    }
+    if (nd != 14) return false;
+    const int64_t year = d[0] * 1000 + d[1] * 100 + d[2] * 10 + d[3];
+    const int mon = (int)(d[4] * 10 + d[5]) - 1;  // -1 .. 98
+    const int64_t mday = d[6] * 10 + d[7], hour = d[8] * 10 + d[9], min = d[10] * 10 + d[11], sec = d[12] * 10 + d[13];
+    int mon_rem = mon % 12, mon_years = mon / 12;
+    if (mon_rem < 0) {
+        mon_rem += 12;
+        --mon_years;
+    }
+    const int64_t y = year + mon_years;
+    const bool leap = (y % 4 == 0) && (y % 100 != 0 || y % 400 == 0);
+    const int before[12] = {0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334};
+    const int64_t yday = before[mon_rem] + ((leap && mon_rem > 1) ? 1 : 0) + mday - 1;
+    // days from 1970-01-01 to January 1st of year y (y >= 0 here; floor divisions of y - 1 >= -1)
+    const int64_t y1 = y - 1;
+    auto fdiv = [](int64_t a, int64_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+    const int64_t days = 365 * (y - 1970) + (fdiv(y1, 4) - fdiv(1969, 4)) - (fdiv(y1, 100) - fdiv(1969, 100)) +
+                         (fdiv(y1, 400) - fdiv(1969, 400)) + yday;
+    const int64_t t = ((days * 24 + hour) * 60 + min) * 60 + sec - tz_offset;
+    value = (uint64_t)t;
+    return true;
+}
 
 struct u128 {
     uint64_t hi, lo;

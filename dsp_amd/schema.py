@@ -11,7 +11,7 @@ from dataclasses import dataclass
 from typing import Iterable, List, Optional, Sequence
 
 # typed conversions (values shared with include/mdc_parse.h and oracle/mdc_oracle.h)
-T_NONE, T_I32, T_U32, T_I64, T_U64, T_F64, T_F32, T_BOOL = range(8)
+T_NONE, T_I32, T_U32, T_I64, T_U64, T_F64, T_F32, T_BOOL, T_TIME = range(9)
 
 
 class CCol(ctypes.Structure):

@@ -53,6 +53,11 @@ enum {
     MDC_T_F64 = 5,  /* stod(picknumber(s,true,true))  -> IEEE-754 binary64 bits          */
     MDC_T_F32 = 6,  /* stof(picknumber(s,true,true))  -> binary32 bits in the low word   */
     MDC_T_BOOL = 7, /* toupper(s)=="TRUE"             -> 0/1                             */
+    MDC_T_TIME = 8, /* strtotime(s) (public/_public.cpp:1009-1044): the digits of the text   */
+                    /* must be exactly 14, yyyymmddhh24miss -> time_t in the int64 slot, as  */
+                    /* mktime gives it (fields out of range carried over) in a zone without  */
+                    /* daylight saving, mdc_opts.tz_offset seconds east of UTC; not valid    */
+                    /* where strtotime returns -1 for the format                             */
     MDC_T_DEFAULT = -1 /* number -> F64, date -> I64, char -> NONE                       */
 };
 
@@ -82,6 +87,8 @@ typedef struct mdc_opts {
                          /* getxmlbuffer per column (missing tag: empty cell, found bit 0)  */
     const int *typed;    /* per column MDC_T_*; NULL = MDC_T_DEFAULT for every column       */
     unsigned flags;      /* MDC_F_*                                                          */
+    int tz_offset;       /* MDC_T_TIME columns: the zone strtotime's mktime would run in,    */
+                         /* seconds east of UTC (28800 for the reference's UTC+8 sites)     */
 } mdc_opts;
 
 enum {

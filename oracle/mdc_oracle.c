@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------ small helpers */
 
@@ -215,6 +216,30 @@ int ORC_FN(convert)(const uint8_t *s, size_t n, int type, uint64_t *out8) {
             istrue = memcmp(t, "TRUE", 4) == 0;
         }
         *out8 = (uint64_t)istrue;
+        return 1;
+    }
+    if (type == ORC_T_TIME) {
+        /* strtotime, public/_public.cpp:1009-1044: the digits (picknumber without sign and
+         * point) must be fourteen; yyyy mm dd hh mi ss go to mktime (libc, the process's zone)
+         * with tm_isdst = 0.  Its "return -1" for any other count is the failure here. */
+        char d[14];
+        size_t nd = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (s[i] >= '0' && s[i] <= '9') {
+                if (nd < 14) d[nd] = (char)s[i];
+                ++nd;
+            }
+        if (nd != 14) return 0;
+        struct tm tmv;
+        memset(&tmv, 0, sizeof tmv);
+        tmv.tm_year = (d[0] - '0') * 1000 + (d[1] - '0') * 100 + (d[2] - '0') * 10 + (d[3] - '0') - 1900;
+        tmv.tm_mon = (d[4] - '0') * 10 + (d[5] - '0') - 1;
+        tmv.tm_mday = (d[6] - '0') * 10 + (d[7] - '0');
+        tmv.tm_hour = (d[8] - '0') * 10 + (d[9] - '0');
+        tmv.tm_min = (d[10] - '0') * 10 + (d[11] - '0');
+        tmv.tm_sec = (d[12] - '0') * 10 + (d[13] - '0');
+        tmv.tm_isdst = 0;
+        *out8 = (uint64_t)(int64_t)mktime(&tmv);
         return 1;
     }
     int bsigned = (type == ORC_T_I32 || type == ORC_T_I64 || type == ORC_T_F64 || type == ORC_T_F32);

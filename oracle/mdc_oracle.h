@@ -40,7 +40,8 @@ enum {
     ORC_T_U64 = 4,  /* stoul(picknumber(s))            */
     ORC_T_F64 = 5,  /* stod(picknumber(s,true,true))   */
     ORC_T_F32 = 6,  /* stof(picknumber(s,true,true))   */
-    ORC_T_BOOL = 7  /* toupper(s)=="TRUE"              */
+    ORC_T_BOOL = 7, /* toupper(s)=="TRUE"              */
+    ORC_T_TIME = 8  /* strtotime(s), public/_public.cpp:1009-1044, in the process's time zone */
 };
 
 /* Columnar result of parsing a whole buffer; same layout as the GPU batch.

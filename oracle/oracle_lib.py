@@ -16,7 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-T_NONE, T_I32, T_U32, T_I64, T_U64, T_F64, T_F32, T_BOOL = range(8)
+T_NONE, T_I32, T_U32, T_I64, T_U64, T_F64, T_F32, T_BOOL, T_TIME = range(9)
 
 
 class _CCol(ctypes.Structure):

@@ -116,6 +116,14 @@ bool convert_text(const std::string &text, int type, uint64_t *out8) {
         *out8 = v ? 1 : 0;
         return true;
     }
+    case ORC_T_TIME: {
+        /* strtotime (public/_public.cpp:1009-1044) in the process's time zone; its -1 for a text
+         * without fourteen digits is told from a time of -1 by the digit count */
+        time_t t = strtotime(text);
+        if (t == (time_t)-1 && picknumber(text, false, false).length() != 14) return false;
+        *out8 = (uint64_t)(int64_t)t;
+        return true;
+    }
     default:
         return false;
     }
