@@ -298,8 +298,8 @@ struct TagKey {
     uint32_t lo, hi;
 };
 __device__ __forceinline__ TagKey tag_key(const uint8_t *sdata, uint32_t q) {
-    const uint64_t w = lds_u64(sdata + q + 1);
-    uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+    uint32_t lo, hi, w2;
+    lds_bytes12(sdata + q + 1, lo, hi, w2);
     const uint32_t glo = bytes_eq7(lo, 0x3E3E3E3Eu), ghi = bytes_eq7(hi, 0x3E3E3E3Eu);
     if (glo) {
         const uint32_t g = (uint32_t)__builtin_ctz(glo) >> 3;
