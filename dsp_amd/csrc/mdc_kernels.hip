@@ -815,8 +815,8 @@ __device__ __forceinline__ bool cell_fast(uint64_t lo, uint64_t hi, uint32_t len
         yhi = sh ? (xhi << sh) | (xlo >> (64 - sh)) : xhi;
         ylo = xlo << sh;
     }
-    const uint32_t hi8 = parse4((uint32_t)ylo) * 10000u + parse4((uint32_t)(ylo >> 32));
-    const uint32_t lo8 = parse4((uint32_t)yhi) * 10000u + parse4((uint32_t)(yhi >> 32));
+    const uint32_t hi8 = __umul24(parse4((uint32_t)ylo), 10000u) + parse4((uint32_t)(ylo >> 32));
+    const uint32_t lo8 = __umul24(parse4((uint32_t)yhi), 10000u) + parse4((uint32_t)(yhi >> 32));
     const uint64_t m = (uint64_t)hi8 * 100000000ull + lo8;
     switch (typed) {
     case T_I32:
@@ -899,8 +899,8 @@ __device__ __forceinline__ bool cell_simple(const uint4 &w4, uint32_t len, uint3
     const uint32_t t = sh & 63;
     const uint64_t yhi = (sh & 128) ? 0ull : (up << t) | (t ? dn >> (64 - t) : 0ull);
     const uint64_t ylo = (sh & 128) ? 0ull : dn << t;
-    const uint32_t hi8 = parse4((uint32_t)ylo) * 10000u + parse4((uint32_t)(ylo >> 32));
-    const uint32_t lo8 = parse4((uint32_t)yhi) * 10000u + parse4((uint32_t)(yhi >> 32));
+    const uint32_t hi8 = __umul24(parse4((uint32_t)ylo), 10000u) + parse4((uint32_t)(ylo >> 32));
+    const uint32_t lo8 = __umul24(parse4((uint32_t)yhi), 10000u) + parse4((uint32_t)(yhi >> 32));
     const uint64_t m = (uint64_t)hi8 * 100000000ull + lo8;
     const bool issigned = (typed == T_I32) | (typed == T_I64) | (typed == T_F64);
     const bool neg = keep & issigned & (sg != 0) & (c0 == '-');
