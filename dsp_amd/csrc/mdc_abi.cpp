@@ -357,30 +357,40 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
             memcpy(&q.hi, key + 4, 4);
             pats.push_back(q);
         }
-    // the smallest table (a power of two, 1.4 slots per pattern at least) for which a seed
-    // exists: every 32-byte slot is LDS that the kernels would rather spend on resident blocks
+    // The smallest table (a power of two, 1.4 slots per pattern at least) for which a seed puts
+    // all distinct keys into slots of their own: every 32-byte slot is LDS that the kernels would
+    // rather spend on resident blocks.  Twice that size is tried as well; where no such seed
+    // exists (many similar names) the seed with the fewest shared slots is taken and the keys
+    // that share a slot are chained.
     uint32_t ht_size = 16, seed = 0;
     while (ht_size * 5 < npat * 7) ht_size <<= 1;
-    std::vector<int> head;  // slot -> first pattern index with that key, or -1
-    for (;;) {
-        bool ok = false;
-        for (seed = 0; seed < 65536 && !ok; ++seed) {
-            head.assign(ht_size, -1);
-            ok = true;
-            for (size_t i = 0; i < pats.size() && ok; ++i) {
-                uint32_t slot = ht_hash(pats[i].lo, pats[i].hi, seed * 0x9E3779B9u) & (ht_size - 1);
-                if (head[slot] < 0)
-                    head[slot] = (int)i;
-                else if (pats[head[slot]].lo != pats[i].lo || pats[head[slot]].hi != pats[i].hi)
-                    ok = false;  // two different keys in one slot
+    std::vector<int> head;  // slot -> first pattern index that lands there, or -1
+    {
+        uint32_t best_size = ht_size, best_seed = 0, best_shared = 0xFFFFFFFFu;
+        for (uint32_t size = ht_size; size <= 2 * ht_size && best_shared; size <<= 1)
+            for (uint32_t sd = 0; sd < 16384 && best_shared; ++sd) {
+                head.assign(size, -1);
+                uint32_t shared = 0;
+                for (size_t i = 0; i < pats.size() && shared < best_shared; ++i) {
+                    const uint32_t slot = ht_hash(pats[i].lo, pats[i].hi, sd * 0x9E3779B9u) & (size - 1);
+                    if (head[slot] < 0)
+                        head[slot] = (int)i;
+                    else if (pats[head[slot]].lo != pats[i].lo || pats[head[slot]].hi != pats[i].hi)
+                        ++shared;  // (another key than the slot's first: counted once per pattern)
+                }
+                if (shared < best_shared) {
+                    best_shared = shared;
+                    best_size = size;
+                    best_seed = sd;
+                }
             }
+        ht_size = best_size;
+        seed = best_seed;
+        head.assign(ht_size, -1);
+        for (size_t i = 0; i < pats.size(); ++i) {
+            const uint32_t slot = ht_hash(pats[i].lo, pats[i].hi, seed * 0x9E3779B9u) & (ht_size - 1);
+            if (head[slot] < 0) head[slot] = (int)i;
         }
-        if (ok) {
-            --seed;
-            break;
-        }
-        ht_size <<= 1;
-        if (ht_size > 4096) return fail(MDC_ERR_INTERNAL, "could not build the tag hash table");
     }
     seed *= 0x9E3779B9u;
     // chained entries (same key) go behind the hashed slots

@@ -71,15 +71,21 @@ static_assert(sizeof(DevCol) == 40, "DevCol layout");
 
 // hash of a tag key (the first eight bytes of text+'>' as two little-endian words)
 MDC_HD inline uint32_t ht_hash(uint32_t lo, uint32_t hi, uint32_t seed) {
-    uint32_t h = (lo ^ seed) * 0x9E3779B1u + hi * 0x85EBCA77u;
-    return h ^ (h >> 15);
+    // (tag names of one table tend to differ in one or two bytes only: two multiplications with a
+    // fold between them spread those over the low bits the slot index is taken from)
+    uint32_t h = (lo ^ seed) * 0x9E3779B1u;
+    h ^= h >> 15;
+    h = (h + hi) * 0x85EBCA77u;
+    return h ^ (h >> 13);
 }
 
-// Perfect-hash table of tag texts: the host picks a seed under which all distinct keys fall
-// into distinct slots, so a lookup is ONE probe.  key = first min(8, tlen+1) bytes of
-// text+'>'; bytes 8..15 of text+'>' are compared through (k2 & m2); entries whose key is
-// shared (duplicate column names, names equal in their first eight bytes) are chained through
-// `next` (index into the same array, 0 = end; chain entries live behind the hashed slots).
+// Hash table of tag texts.  The host looks for a seed under which all distinct keys fall into
+// distinct slots, so that a lookup is ONE probe; where it finds none (wide schemas of similar
+// names) it takes the seed with the fewest shared slots.  key = first min(8, tlen+1) bytes of
+// text+'>'; bytes 8..15 of text+'>' are compared through (k2 & m2).  Entries that share a slot
+// (another key, duplicate column names, names equal in their first eight bytes) are chained
+// through `next` (index into the same array, 0 = end; chain entries live behind the hashed
+// slots); a lookup compares the key of every entry of the chain.
 struct HtEntry {
     uint32_t klo, khi;
     uint32_t meta;  // bit31 used | bit30 text longer than 16 bytes | col<<16 | kind<<8 | tlen

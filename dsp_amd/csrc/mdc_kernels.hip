@@ -320,14 +320,15 @@ __device__ __forceinline__ uint32_t tag_slot(const SchemaHdr *H, const TagKey &k
 __device__ __forceinline__ void tag_apply(const uint8_t *sdata, const DevCol *cols, const HtEntry *ht, uint32_t q,
                                           const TagKey &k, uint32_t slot, const uint4 &e0, uint32_t *evt, uint32_t rl,
                                           uint32_t RB) {
-    if (!(e0.z >> 31) || e0.x != k.lo || e0.y != k.hi) return;
+    if (!(e0.z >> 31)) return;                               // nothing hashes to this slot
+    if ((e0.x != k.lo || e0.y != k.hi) && !e0.w) return;    // (the common miss: another key, no chain)
     const uint32_t a = q + 1;
     for (;;) {
         const HtEntry &e = ht[slot];
         const uint32_t meta = e.meta;
         const uint32_t tlen = meta & 0xFFu, kind = (meta >> 8) & 1u, col = (meta >> 16) & 0x3FFFu;
-        bool ok = true;
-        if (tlen >= 8) {  // the key covers eight bytes; compare the rest of text+'>'
+        bool ok = e.klo == k.lo && e.khi == k.hi;
+        if (ok && tlen >= 8) {  // the key covers eight bytes; compare the rest of text+'>'
             const uint64_t w2 = lds_u64(sdata + a + 8);
             ok = (((uint32_t)w2 ^ e.k2lo) & e.m2lo) == 0 && (((uint32_t)(w2 >> 32) ^ e.k2hi) & e.m2hi) == 0;
             if (ok && (meta & 0x40000000u)) {
@@ -360,15 +361,15 @@ __device__ __forceinline__ uint32_t tag_lookup(const uint8_t *sdata, const Schem
     const TagKey k = tag_key(sdata, q);
     uint32_t slot = tag_slot(H, k);
     const HtEntry &f = ht[slot];
-    if (!(f.meta >> 31) || f.klo != k.lo || f.khi != k.hi) return 0;
+    if (!(f.meta >> 31)) return 0;
     const uint32_t a = q + 1;
     uint32_t n = 0;
     for (;;) {
         const HtEntry &e = ht[slot];
         const uint32_t meta = e.meta;
         const uint32_t tlen = meta & 0xFFu, kind = (meta >> 8) & 1u, col = (meta >> 16) & 0x3FFFu;
-        bool ok = true;
-        if (tlen >= 8) {
+        bool ok = e.klo == k.lo && e.khi == k.hi;
+        if (ok && tlen >= 8) {
             const uint64_t w2 = lds_u64(sdata + a + 8);
             ok = (((uint32_t)w2 ^ e.k2lo) & e.m2lo) == 0 && (((uint32_t)(w2 >> 32) ^ e.k2hi) & e.m2hi) == 0;
             if (ok && (meta & 0x40000000u)) {

@@ -268,6 +268,21 @@ def test_tag_template_follows_the_input(port):
     p.close()
 
 
+@pytest.mark.parametrize("ncols", [20, 33, 64, 128])
+def test_wide_schemas_with_and_without_room_for_the_template(port, ncols):
+    """Regular records under schemas of growing width: the template's entries and column plan fit
+    the sizing pass's LDS for the narrow ones only; beyond that (and beyond 64 events per record)
+    every tile takes the table lookup.  Every third column is missing (values carry over)."""
+    cols = [Col("c%d" % i, ("number", "date", "char")[i % 3], (22, 14, 8)[i % 3]) for i in range(ncols)]
+    recs = []
+    for r in range(3000):
+        recs.append(b"".join(b"<c%d>%d.%d</c%d>" % (i, (r * 7 + i) % 1000, i % 10, i) for i in range(ncols) if i % 3 != 1 or r % 50 == 0)
+                    + b"<endl/>\n")
+    data = b"<data>\n" + b"".join(recs) + b"</data>\n"
+    got = gpu_xml(data, cols)
+    assert_batches_equal(got, port.parse_xml(data, cols), "ncols=%d" % ncols)
+
+
 def test_many_tiles(port):
     data, n = gen.mind_xml(nbytes=48 << 20)
     p = capi.Parser.xml(schema.ZHOBTMIND)
