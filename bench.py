@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--workload", choices=["xml", "csv"], default="xml")
     ap.add_argument("--bytes", type=int, default=1 << 30, help="batch size per GPU")
     ap.add_argument("--cpu-sample-mb", type=int, default=256, help="0 disables the CPU baseline")
+    ap.add_argument("--cpu-procs", type=int, default=16,
+                    help="processes of the all-cores CPU baseline (one 64 MiB batch each); 0 disables it")
     ap.add_argument("--verify", type=int, default=1, help="check a slice of the output against the CPU checker")
     return ap.parse_args()
 
@@ -77,6 +79,28 @@ def cpu_baseline(workload, data, sample_mb):
         "sample": f"first {cut} bytes ({hb.rows} records) of the rank-0 batch, {dt:.2f} s"
                   + (", incl. the reference reading it back from a temp file" if kind == "reference" else ""),
     }, hb, cut
+
+
+def cpu_baseline_all_cores(workload, procs):
+    """How the reference scales in deployment: one single-threaded process per share of the
+    files.  `procs` worker processes (tools/cpu_slice.py), each with a 64 MiB batch of its own,
+    started together; the rate is all their bytes over the slowest one's time."""
+    import subprocess
+    procs = max(1, min(procs, os.cpu_count() or 1))
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_slice.py"), workload, str(64 << 20)]
+    ps = [subprocess.Popen(cmd + [str(20_000_000 + 1_000_000 * i)], stdout=subprocess.PIPE, text=True) for i in range(procs)]
+    res = []
+    for p in ps:
+        out, _ = p.communicate(timeout=300)
+        if p.returncode != 0:
+            return None
+        res.append(json.loads(out.strip().splitlines()[-1]))
+    slowest = max(r["seconds"] for r in res)
+    return {
+        "value": round(sum(r["bytes"] for r in res) / slowest / 1e9, 4), "unit": "GB/s", "cores": procs,
+        "kind": res[0]["kind"], "records_per_s": round(sum(r["rows"] for r in res) / slowest, 1),
+        "sample": f"{procs} processes, one 64 MiB batch each, slowest {slowest:.2f} s",
+    }
 
 
 def measured_traffic(kernel, nbytes):
@@ -212,6 +236,8 @@ def main():
         if a.cpu_sample_mb > 0 and world == 1:
             cb, _, _ = cpu_baseline(a.workload, data, a.cpu_sample_mb)
             out["cpu_baseline"] = cb
+            if a.cpu_procs > 0:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(a.workload, a.cpu_procs)
         elif a.cpu_sample_mb > 0:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
