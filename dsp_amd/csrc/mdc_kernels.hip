@@ -858,31 +858,37 @@ __device__ __forceinline__ bool cell_fast(uint64_t lo, uint64_t hi, uint32_t len
 // and date), or when it is an untyped text cell of that length.  Everything is computed without a
 // per-lane branch; the caller takes the results only when all lanes of the pass report true, and
 // runs the general code otherwise.  `typed` is the same for the whole wave.
+// SHORT: every cell of the wave has at most 8 source bytes (most numbers): half the window, half
+// the work.
+template <bool SHORT>
 __device__ __forceinline__ bool cell_simple(const uint4 &w4, uint32_t len, uint32_t lvl, uint32_t typed, bool convert,
                                             const double *p10, uint32_t &flen, uint64_t &elo, uint64_t &ehi,
                                             uint64_t &value, bool &valid) {
+    constexpr uint32_t CAP = SHORT ? 8 : 16;
     const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
-    const uint64_t hi = (uint64_t)w4.z | ((uint64_t)w4.w << 32);
-    const uint32_t lenc = len < 16 ? len : 16;
+    const uint64_t hi = SHORT ? 0ull : (uint64_t)w4.z | ((uint64_t)w4.w << 32);
+    const uint32_t lenc = len < CAP ? len : CAP;
     const uint32_t Lm = (1u << lenc) - 1;
-    const uint32_t D16 = digit_mask16(w4);
+    const uint32_t D16 = SHORT ? __builtin_amdgcn_udot4(digit_flags(w4.y), 0x80402010u,
+                                                        __builtin_amdgcn_udot4(digit_flags(w4.x), 0x08040201u, 0u, false), false) >> 7
+                               : digit_mask16(w4);
     const uint32_t D = D16 & Lm, N = ~D16 & Lm;
     const uint32_t c0 = (uint32_t)lo & 0xFFu;
     const uint32_t sg = N & (uint32_t)((c0 == '+') | (c0 == '-'));  // 1: a sign in front
     const uint32_t N1 = N & ~sg;                                     // the other bytes that are no digits
-    const uint32_t p = (uint32_t)__builtin_ctz(N1 | 0x10000u);       // the first of them (16: none)
-    const uint32_t cp = win_byte(lo, hi, p & 15);
+    const uint32_t p = (uint32_t)__builtin_ctz(N1 | (1u << CAP));    // the first of them (CAP: none)
+    const uint32_t cp = SHORT ? (uint32_t)(lo >> (8 * (p & 7))) & 0xFFu : win_byte(lo, hi, p & 15);
     const uint32_t nd = (uint32_t)__builtin_popcount(D);
     const bool isdate = lvl == LVL_DATE;
-    bool simple = (len <= 16) & ((N1 & (N1 - 1)) == 0) & ((N1 == 0) | (cp == '.')) & !(isdate & (sg != 0));
-    if (typed == T_F64) simple &= nd <= 15;  // (more digits may pass 2^53: the second stage divides exactly)
-    if (typed == T_NONE) simple |= (lvl == LVL_CHAR) & (len <= 16);
-    // the window without the decimal point (p == 16: as it is)
-    const uint64_t slo = (lo >> 8) | (hi << 56), shi = hi >> 8;
+    bool simple = (len <= CAP) & ((N1 & (N1 - 1)) == 0) & ((N1 == 0) | (cp == '.')) & !(isdate & (sg != 0));
+    if (!SHORT && typed == T_F64) simple &= nd <= 15;  // (more digits may pass 2^53: the second stage divides exactly)
+    if (typed == T_NONE) simple |= (lvl == LVL_CHAR) & (len <= CAP);
+    // the window without the decimal point (p == CAP: as it is)
+    const uint64_t slo = SHORT ? lo >> 8 : (lo >> 8) | (hi << 56), shi = hi >> 8;
     const uint32_t pl = p < 8 ? p : 8, ph = p < 8 ? 0 : p - 8;  // bytes kept in place in either half
     const uint64_t klo = pl < 8 ? ~(~0ull << (8 * pl)) : ~0ull;
     const uint64_t khi = ph < 8 ? ~(~0ull << (8 * ph)) : ~0ull;
-    const uint64_t xlo = (lo & klo) | (slo & ~klo), xhi = (hi & khi) | (shi & ~khi);
+    const uint64_t xlo = (lo & klo) | (slo & ~klo), xhi = SHORT ? 0ull : (hi & khi) | (shi & ~khi);
     // (plain: apart from the digits there are only the sign and the point, which the number level
     // keeps; the date level keeps the digits)
     flen = isdate ? nd : len;
@@ -891,18 +897,27 @@ __device__ __forceinline__ bool cell_simple(const uint4 &w4, uint32_t len, uint3
     value = 0;
     valid = false;
     if (typed == T_NONE) return simple;
-    // the digits right-aligned in 16 bytes (the sign's byte cleared, what follows the digits
-    // leaves at the top), four at a time to a number
+    // the digits right-aligned (the sign's byte cleared, what follows the digits leaves at the
+    // top), four at a time to a number
     const bool keep = !isdate;  // the date level has taken sign and point away before the conversion
     const uint64_t zlo = xlo & ~(uint64_t)(0xFFu & (0u - sg));
-    const uint32_t sh = 8 * (16 - nd - sg);
-    const uint64_t up = (sh & 64) ? zlo : xhi, dn = (sh & 64) ? 0ull : zlo;
-    const uint32_t t = sh & 63;
-    const uint64_t yhi = (sh & 128) ? 0ull : (up << t) | (t ? dn >> (64 - t) : 0ull);
-    const uint64_t ylo = (sh & 128) ? 0ull : dn << t;
-    const uint32_t hi8 = __umul24(parse4((uint32_t)ylo), 10000u) + parse4((uint32_t)(ylo >> 32));
-    const uint32_t lo8 = __umul24(parse4((uint32_t)yhi), 10000u) + parse4((uint32_t)(yhi >> 32));
-    const uint64_t m = (uint64_t)hi8 * 100000000ull + lo8;
+    uint64_t m;
+    uint32_t m32 = 0;
+    if (SHORT) {
+        const uint32_t sh = 8 * (8 - nd - sg);
+        const uint64_t y = (sh & 64) ? 0ull : zlo << sh;
+        m32 = __umul24(parse4((uint32_t)y), 10000u) + parse4((uint32_t)(y >> 32));
+        m = m32;
+    } else {
+        const uint32_t sh = 8 * (16 - nd - sg);
+        const uint64_t up = (sh & 64) ? zlo : xhi, dn = (sh & 64) ? 0ull : zlo;
+        const uint32_t t = sh & 63;
+        const uint64_t yhi = (sh & 128) ? 0ull : (up << t) | (t ? dn >> (64 - t) : 0ull);
+        const uint64_t ylo = (sh & 128) ? 0ull : dn << t;
+        const uint32_t hi8 = __umul24(parse4((uint32_t)ylo), 10000u) + parse4((uint32_t)(ylo >> 32));
+        const uint32_t lo8 = __umul24(parse4((uint32_t)yhi), 10000u) + parse4((uint32_t)(yhi >> 32));
+        m = (uint64_t)hi8 * 100000000ull + lo8;
+    }
     const bool issigned = (typed == T_I32) | (typed == T_I64) | (typed == T_F64);
     const bool neg = keep & issigned & (sg != 0) & (c0 == '-');
     bool ok = nd != 0;
@@ -922,7 +937,7 @@ __device__ __forceinline__ bool cell_simple(const uint4 &w4, uint32_t len, uint3
         break;
     default: {  // T_F64: both operands exact (fewer than 16 digits, at most 15 behind the point): one rounding
         const uint32_t k10 = keep ? (uint32_t)__builtin_popcount(D >> (p + 1)) : 0u;
-        const double x = (double)m / p10[k10];
+        const double x = (SHORT ? (double)m32 : (double)m) / p10[k10];
         v = (uint64_t)__double_as_longlong(x) | (neg ? 1ull << 63 : 0ull);
         break;
     }
@@ -1039,8 +1054,11 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
             tyu = (uint32_t)__builtin_amdgcn_readfirstlane((int)tyu);  // (the wave's, in a scalar register)
             const bool act = r < RBn;
             const uint4 w4 = lds_u128(sdata + cs_[ps]);  // (a lane without a record reads the image's first bytes)
-            const bool sc = cell_simple(w4, act ? cl_[ps] : 0u, cv_[ps], tyu, tyu != T_NONE && (fd_[ps] || E.nulcut), E.p10,
-                                        flen, elo, ehi, value, valid);
+            const uint32_t lenp = act ? cl_[ps] : 0u;
+            const bool conv = tyu != T_NONE && (fd_[ps] || E.nulcut);
+            const bool sc = __builtin_amdgcn_ballot_w64(lenp > 8) == 0
+                                ? cell_simple<true>(w4, lenp, cv_[ps], tyu, conv, E.p10, flen, elo, ehi, value, valid)
+                                : cell_simple<false>(w4, lenp, cv_[ps], tyu, conv, E.p10, flen, elo, ehi, value, valid);
             plain = __builtin_amdgcn_ballot_w64(!sc) == 0 && (typed == tyu || typed == T_NONE);
             if (plain) {
                 fast = true;
