@@ -213,6 +213,19 @@ __device__ __forceinline__ void lds_bytes12(const uint8_t *p, uint32_t &w0, uint
     w1 = __builtin_amdgcn_alignbyte(b[0], a[1], sh);
     w2 = __builtin_amdgcn_alignbyte(b[1], b[0], sh);
 }
+// bytes [p, p + 8)
+__device__ __forceinline__ void lds_bytes8(const uint8_t *p, uint32_t &w0, uint32_t &w1) {
+    const uint32_t addr = (uint32_t)(size_t)p;
+    const uint32_t base = addr & ~3u, sh = addr & 3u;
+    lds_u32x2 a;
+    uint32_t b;
+    asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(base)
+                 : "memory");
+    w0 = __builtin_amdgcn_alignbyte(a[1], a[0], sh);
+    w1 = __builtin_amdgcn_alignbyte(b, a[1], sh);
+}
 // bytes [p, p + 16)
 __device__ __forceinline__ uint4 lds_bytes16(const uint8_t *p) {
     const uint32_t addr = (uint32_t)(size_t)p;
@@ -1745,14 +1758,25 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                     int l = (int)e - (int)s1;
                     l = l < 0 ? (int)(re - s1) : (cl > 0 && cl < l) ? cl : l;
                     const uint32_t s = have ? s1 : 0u, len = have ? (uint32_t)l : 0u;
-                    const uint4 w4 = lds_bytes16(sdata + s);
-                    const uint32_t D16 = digit_mask16(w4);
+                    uint32_t D16, c0, wp, N1, pp;
                     const uint32_t Lm = (1u << (len < 16 ? len : 16)) - 1;
-                    const uint32_t N = ~D16 & Lm;
-                    const uint32_t c0 = w4.x & 0xFFu;
-                    const uint32_t N1 = N & ~(uint32_t)((c0 == '+') | (c0 == '-'));
-                    const uint32_t pp = (uint32_t)__builtin_ctz(N1 | 0x10000u) & 15u;
-                    const uint32_t wp = pp < 4 ? w4.x : pp < 8 ? w4.y : pp < 12 ? w4.z : w4.w;
+                    if (__builtin_amdgcn_ballot_w64(len > 8) == 0) {  // (most numbers: half the window)
+                        uint32_t w0, w1;
+                        lds_bytes8(sdata + s, w0, w1);
+                        D16 = __builtin_amdgcn_udot4(digit_flags(w1), 0x80402010u,
+                                                     __builtin_amdgcn_udot4(digit_flags(w0), 0x08040201u, 0u, false), false) >> 7;
+                        c0 = w0 & 0xFFu;
+                        N1 = ~D16 & Lm & ~(uint32_t)((c0 == '+') | (c0 == '-'));
+                        pp = (uint32_t)__builtin_ctz(N1 | 0x100u) & 7u;
+                        wp = pp < 4 ? w0 : w1;
+                    } else {
+                        const uint4 w4 = lds_bytes16(sdata + s);
+                        D16 = digit_mask16(w4);
+                        c0 = w4.x & 0xFFu;
+                        N1 = ~D16 & Lm & ~(uint32_t)((c0 == '+') | (c0 == '-'));
+                        pp = (uint32_t)__builtin_ctz(N1 | 0x10000u) & 15u;
+                        wp = pp < 4 ? w4.x : pp < 8 ? w4.y : pp < 12 ? w4.z : w4.w;
+                    }
                     const bool numplain = ((N1 & (N1 - 1)) == 0) & ((N1 == 0) | (((wp >> (8 * (pp & 3))) & 0xFFu) == '.'));
                     const bool ok = (len <= 16) & ((lvl != LVL_NUMBER) | numplain);
                     if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
@@ -2080,12 +2104,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             const ColOut O = colout[c];
             const uint64_t gb = O.base + tiletot[c];
             const uint32_t total =
-#ifdef MDC_EXP_A
-                column_cells<true>(E, O, c, (uint32_t)__builtin_amdgcn_readfirstlane((int)cols[c].typed), lane, RBn,
-                                   row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);  // (the type in a scalar register: its branches are the wave's)
-#else
                 column_cells<true>(E, O, c, cols[c].typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
-#endif
             if (lane == 0) tiletot[c] += total;  // this wave owns column c
         }
         __syncthreads();
