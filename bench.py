@@ -35,8 +35,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20,
+                    help="untimed parses in front (the GPU reaches its steady clocks after 10 to 15 parses of 1 GiB)")
     ap.add_argument("--workload", choices=["xml", "csv"], default="xml")
     ap.add_argument("--bytes", type=int, default=1 << 30, help="batch size per GPU")
     ap.add_argument("--cpu-sample-mb", type=int, default=256, help="0 disables the CPU baseline")

@@ -50,7 +50,7 @@ EXPORTS = [
 FORMAT_EXPORTS = [
     "mdc_formatter_create", "mdc_formatter_destroy", "mdc_format_device", "mdc_format_host", "mdc_format_batch",
     "mdc_formatter_last_timing", "mdc_text_files", "mdc_text_bytes", "mdc_text_file_range", "mdc_text_device",
-    "mdc_text_host", "mdc_text_write_files", "mdc_text_free",
+    "mdc_text_host", "mdc_text_write_files", "mdc_text_free", "mdc_timetostr_device", "mdc_timetostr_width",
 ]
 
 
@@ -171,6 +171,8 @@ def lib():
                                            ci, ctypes.POINTER(ci)]
         L.mdc_text_free.argtypes = [vp]
         L.mdc_text_free.restype = None
+        L.mdc_timetostr_device.argtypes = [ci, vp, i64, ctypes.c_char_p, ci, vp, vp]
+        L.mdc_timetostr_width.argtypes = [ctypes.c_char_p]
         _lib = L
     return _lib
 
@@ -481,3 +483,43 @@ class Formatter:
         t = CFormatTiming()
         check(lib().mdc_formatter_last_timing(self.h, ctypes.byref(t)))
         return t
+
+
+TIME_FORMATS = ["", "yyyy-mm-dd hh24:mi:ss", "yyyy-mm-dd hh24:mi", "yyyy-mm-dd hh24", "yyyy-mm-dd", "yyyy-mm",
+                "yyyymmddhh24miss", "yyyymmddhh24mi", "yyyymmddhh24", "yyyymmdd", "hh24miss", "hh24mi", "hh24", "mi"]
+
+
+def timetostr_width(fmt: str) -> int:
+    """Bytes of the text timetostr gives for fmt (mdc_timetostr_width)."""
+    w = lib().mdc_timetostr_width(fmt.encode())
+    if w < 0:
+        check(w)
+    return w
+
+
+def timetostr_device(d_time: int, rows: int, fmt: str, tz_offset: int, d_off: int, d_bytes: int, device: int = 0):
+    """mdc_timetostr_device on device pointers."""
+    check(lib().mdc_timetostr_device(device, d_time, rows, fmt.encode(), tz_offset, d_off, d_bytes))
+
+
+def timetostr(times: np.ndarray, fmt: str = "", tz_offset: int = 0, device: int = 0, misalign: int = 0):
+    """The texts of a host array of time_t values, through the GPU: (offsets[rows+1], bytes).
+    misalign shifts the byte arena's start (the library takes any alignment)."""
+    times = np.ascontiguousarray(times, dtype=np.int64)
+    rows = int(times.size)
+    w = timetostr_width(fmt)
+    d_t = DeviceBuffer(times.view(np.uint8), device)
+    d_off = DeviceBuffer(np.zeros((rows + 1) * 4, np.uint8), device)
+    d_b = DeviceBuffer(np.zeros(rows * w + 8, np.uint8), device)
+    try:
+        timetostr_device(d_t.ptr, rows, fmt, tz_offset, d_off.ptr, d_b.ptr + misalign, device)
+        off = np.zeros(rows + 1, np.uint32)
+        data = np.zeros(max(rows * w, 1), np.uint8)
+        check(lib().mdc_device_download(device, off.ctypes.data, d_off.ptr, off.nbytes))
+        if rows:
+            check(lib().mdc_device_download(device, data.ctypes.data, d_b.ptr + misalign, rows * w))
+        return off, data[:rows * w]
+    finally:
+        d_t.free()
+        d_off.free()
+        d_b.free()

@@ -40,6 +40,8 @@ hipError_t launch_fixed_stride(const uint32_t *off, const uint8_t *bytes, uint8_
 hipError_t launch_format_prep(const uint32_t *const *off, const uint64_t *nbytes, uint32_t ncols, uint64_t rows,
                               uint64_t *info, hipStream_t stream);
 hipError_t launch_format(bool exact, const FormatParams &P, hipStream_t stream);
+hipError_t launch_timetostr(const int64_t *tv, uint64_t rows, const TimeFmt &F, int32_t tz_offset, uint32_t *off,
+                            uint8_t *bytes, uint32_t *status, hipStream_t stream);
 uint32_t format_scan_parts(uint64_t rows);
 hipError_t launch_format_measure(const FormatParams &P, uint32_t *elen, uint64_t *reclen, uint64_t *part,
                                  uint64_t *recpos, hipStream_t stream);
@@ -1433,6 +1435,81 @@ extern "C" int mdc_format_host(mdc_formatter *f, const uint32_t *const *off, con
                             nbytes.data(), rows, maxcount, out);
     release();
     return rc;
+}
+
+// ---- timetostr in bulk ------------------------------------------------------------------
+// the formats of the reference's timetostr (public/_public.cpp:639-719), each as the bytes it
+// takes from "yyyy-mm-dd hh:mi:ss"
+static bool time_format(const char *fmt, mdc::TimeFmt *F) {
+    static const uint8_t dashed[19] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18};
+    static const uint8_t packed[14] = {0, 1, 2, 3, 5, 6, 8, 9, 11, 12, 14, 15, 17, 18};
+    static const struct {
+        const char *name;
+        const uint8_t *idx;
+        uint32_t from, width;
+    } table[] = {
+        {"", dashed, 0, 19},
+        {"yyyy-mm-dd hh24:mi:ss", dashed, 0, 19},
+        {"yyyy-mm-dd hh24:mi", dashed, 0, 16},
+        {"yyyy-mm-dd hh24", dashed, 0, 13},
+        {"yyyy-mm-dd", dashed, 0, 10},
+        {"yyyy-mm", dashed, 0, 7},
+        {"yyyymmddhh24miss", packed, 0, 14},
+        {"yyyymmddhh24mi", packed, 0, 12},
+        {"yyyymmddhh24", packed, 0, 10},
+        {"yyyymmdd", packed, 0, 8},
+        {"hh24miss", packed, 8, 6},
+        {"hh24mi", packed, 8, 4},
+        {"hh24", packed, 8, 2},
+        {"mi", packed, 10, 2},
+    };
+    for (const auto &e : table)
+        if (strcmp(fmt, e.name) == 0) {
+            memset(F, 0, sizeof *F);
+            F->width = e.width;
+            for (uint32_t k = 0; k < e.width; ++k) F->idx[k] = e.idx[e.from + k];
+            return true;
+        }
+    return false;
+}
+
+extern "C" int mdc_timetostr_width(const char *fmt) {
+    mdc::TimeFmt F;
+    if (!fmt || !time_format(fmt, &F)) return fail(MDC_ERR_ARG, "not one of timetostr's formats");
+    return (int)F.width;
+}
+
+extern "C" int mdc_timetostr_device(int device, const int64_t *d_time, int64_t rows, const char *fmt, int tz_offset,
+                                    uint32_t *d_off, uint8_t *d_bytes) {
+    mdc::TimeFmt F;
+    if (!fmt || !time_format(fmt, &F))
+        return fail(MDC_ERR_ARG, "not one of timetostr's formats (the reference leaves the string as it is)");
+    if (rows < 0) return fail(MDC_ERR_ARG, "negative rows");
+    if (tz_offset <= -86400 || tz_offset >= 86400) return fail(MDC_ERR_ARG, "tz_offset %d is no zone", tz_offset);
+    if (!d_off || (rows && (!d_time || !d_bytes))) return fail(MDC_ERR_ARG, "NULL pointer");
+    if ((uint64_t)rows * F.width > 0xFFFFFFFFull) return fail(MDC_ERR_TOO_LARGE, "the column would exceed 4 GiB: split the rows");
+    Device *d;
+    int rc = get_device(device, &d);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(d->id));
+    if (rows == 0) {
+        const uint32_t zero = 0;
+        HIP_TRY(hipMemcpy(d_off, &zero, 4, hipMemcpyHostToDevice));
+        return MDC_OK;
+    }
+    void *d_status = nullptr;
+    if ((rc = dev_alloc(d, 64, &d_status))) return rc;
+    uint32_t status = 0;
+    hipError_t e = hipMemcpyAsync(d_status, &status, 4, hipMemcpyHostToDevice, d->stream);
+    if (e == hipSuccess)
+        e = mdc::launch_timetostr(d_time, (uint64_t)rows, F, tz_offset, d_off, d_bytes, (uint32_t *)d_status, d->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    dev_free(d, d_status);
+    if (e != hipSuccess) return fail(MDC_ERR_HIP, "timetostr: %s", hipGetErrorString(e));
+    if (status)
+        return fail(MDC_ERR_NUMERIC, "a time lies outside the years 0000 to 9999 (its text would not have the format's width)");
+    return MDC_OK;
 }
 
 extern "C" int mdc_formatter_last_timing(const mdc_formatter *f, mdc_format_timing *t) {

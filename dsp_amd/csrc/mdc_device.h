@@ -204,4 +204,12 @@ struct FormatParams {
     uint32_t lds_ptrs, lds_cpos, lds_src, lds_rstart, lds_rflag, lds_misc, lds_stage, stage_cap, lds_total;
 };
 
+// One of timetostr's formats (reference public/_public.cpp:631-722) as a selection of bytes of
+// "yyyy-mm-dd hh:mi:ss": byte k of the text is byte idx[k] of that string.
+constexpr int TT_BLOCK = 256;
+struct TimeFmt {
+    uint32_t width;
+    uint8_t idx[20];
+};
+
 }  // namespace mdc

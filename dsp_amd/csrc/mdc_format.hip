@@ -586,4 +586,93 @@ hipError_t launch_format_measure(const FormatParams &P, uint32_t *elen, uint64_t
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// timetostr in bulk (reference public/_public.cpp:631-722): time_t values -> the text of one of
+// the reference's thirteen formats, one cell per row in the layout the formatter and the
+// parser's batches use (u32 end offsets + bytes; the cells all have the format's width).
+// localtime_r is taken for a zone without daylight saving (tz_offset seconds east of UTC).
+// Every format is a selection of bytes of "yyyy-mm-dd hh:mi:ss": a block writes that text for
+// its rows into LDS, then its piece of the column (TT_BLOCK x width bytes, a multiple of four)
+// goes out in dword stores.
+constexpr int64_t TT_MIN = -62167219200ll;   // 0000-01-01 00:00:00
+constexpr int64_t TT_MAX = 253402300799ll;   // 9999-12-31 23:59:59
+__device__ __forceinline__ uint32_t two_digits(uint32_t v) {  // "ab" of v = 10a + b as two bytes, first byte low
+    const uint32_t a = (v * 205u) >> 11;  // v / 10 for v < 100
+    return (0x30u + a) | ((0x30u + v - 10u * a) << 8);
+}
+__global__ __launch_bounds__(TT_BLOCK) void timetostr_kernel(const int64_t *tv, uint64_t rows, const TimeFmt F,
+                                                             int32_t tz_offset, uint32_t *off, uint8_t *bytes,
+                                                             uint32_t aligned, uint32_t *status) {
+    __shared__ __align__(4) uint8_t full[TT_BLOCK * 20];
+    __shared__ uint8_t sidx[20];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t row0 = (uint64_t)blockIdx.x * TT_BLOCK;
+    const uint64_t row = row0 + tid;
+    const uint32_t width = F.width;
+    if (tid < 20) sidx[tid] = F.idx[tid];
+    if (row < rows) {
+        int64_t local = tv[row] + (int64_t)tz_offset;
+        if (local < TT_MIN || local > TT_MAX) {  // (the year would not print as four digits)
+            atomicOr(status, 1u);
+            local = 0;
+        }
+        int64_t days = local / 86400;
+        int32_t sod = (int32_t)(local - days * 86400);
+        if (sod < 0) {
+            sod += 86400;
+            --days;
+        }
+        // civil date of a day count (days since 1970-01-01), proleptic Gregorian calendar
+        // days since 0000-03-01 of one 400-year cycle earlier (January and February of the year
+        // 0000 lie in front of that day): >= 0 in the accepted range
+        const int64_t z = days + 719468 + 146097;
+        const uint32_t era = (uint32_t)(z / 146097);
+        const uint32_t doe = (uint32_t)(z - (int64_t)era * 146097);
+        const uint32_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+        const uint32_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+        const uint32_t mp = (5 * doy + 2) / 153;
+        const uint32_t mday = doy - (153 * mp + 2) / 5 + 1;
+        const uint32_t mon = mp < 10 ? mp + 3 : mp - 9;
+        const uint32_t year = yoe + era * 400 + (mon <= 2 ? 1u : 0u) - 400u;
+        const uint32_t hour = (uint32_t)sod / 3600, rem = (uint32_t)sod - hour * 3600;
+        const uint32_t mi = rem / 60, sec = rem - mi * 60;
+        const uint32_t yh = year / 100, yl = year - yh * 100;
+        // "yyyy-mm-dd hh:mi:ss" + one unused byte, as five words
+        uint32_t *w = (uint32_t *)(full + tid * 20);
+        const uint32_t mm = two_digits(mon), dd = two_digits(mday), hh = two_digits(hour), mn = two_digits(mi),
+                       ss = two_digits(sec);
+        w[0] = two_digits(yh) | (two_digits(yl) << 16);
+        w[1] = 0x2Du | (mm << 8) | (0x2Du << 24);
+        w[2] = dd | (0x20u << 16) | ((hh & 0xFFu) << 24);
+        w[3] = (hh >> 8) | (0x3Au << 8) | (mn << 16);
+        w[4] = 0x3Au | (ss << 8);
+        off[row + 1] = (uint32_t)((row + 1) * width);
+    }
+    if (row == 0) off[0] = 0;
+    __syncthreads();
+    const uint32_t nrows = rows - row0 < (uint64_t)TT_BLOCK ? (uint32_t)(rows - row0) : (uint32_t)TT_BLOCK;
+    const uint32_t nbytes = nrows * width;
+    uint8_t *dst = bytes + row0 * width;
+    auto out_byte = [&](uint32_t o) -> uint32_t {
+        const uint32_t r = o / width;
+        return full[r * 20 + sidx[o - r * width]];
+    };
+    const uint32_t nwords = aligned ? nbytes / 4 : 0;
+    for (uint32_t i = tid; i < nwords; i += TT_BLOCK) {
+        const uint32_t o = i * 4;
+        ((uint32_t *)dst)[i] = out_byte(o) | (out_byte(o + 1) << 8) | (out_byte(o + 2) << 16) | (out_byte(o + 3) << 24);
+    }
+    for (uint32_t o = nwords * 4 + tid; o < nbytes; o += TT_BLOCK) dst[o] = (uint8_t)out_byte(o);
+}
+
+hipError_t launch_timetostr(const int64_t *tv, uint64_t rows, const TimeFmt &F, int32_t tz_offset, uint32_t *off,
+                            uint8_t *bytes, uint32_t *status, hipStream_t stream) {
+    const uint64_t nb = (rows + TT_BLOCK - 1) / TT_BLOCK;
+    if (nb == 0 || nb > 0x7fffffffull || F.width == 0 || F.width > 19) return hipErrorInvalidValue;
+    const uint32_t aligned = ((uintptr_t)bytes & 3u) == 0;
+    hipLaunchKernelGGL(timetostr_kernel, dim3((uint32_t)nb), dim3(TT_BLOCK), 0, stream, tv, rows, F, tz_offset, off, bytes,
+                       aligned, status);
+    return hipGetLastError();
+}
+
 } // namespace mdc

@@ -72,6 +72,7 @@ class Route:
     """The entries of a parameter file (loadxmltotable) and the lookup by file name."""
 
     def __init__(self, data: Optional[bytes] = None, path: Optional[str] = None):
+        self.h = None
         h = ctypes.c_void_p()
         if path is not None:
             rc = _lib().mdc_route_load(_enc(path), ctypes.byref(h))

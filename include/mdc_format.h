@@ -83,6 +83,26 @@ int mdc_text_write_files(mdc_text *t, const char *outpath, const char *bfilename
                          const char *efilename, int first_seq, int *nwritten);
 void mdc_text_free(mdc_text *t);
 
+/* ---- times as text ---------------------------------------------------------------------
+ * timetostr(ttime, strtime, fmt) of the reference (public/_public.cpp:631-722) over a column of
+ * time_t values in device memory: row i becomes the text the reference prints for d_time[i] in
+ * format fmt, written as a column in the layout of the parser's batches and of
+ * mdc_format_device: d_off receives rows+1 u32 offsets (i x width), d_bytes rows x width bytes,
+ * both caller-allocated device memory on `device` (mdc_device_alloc).  fmt is one of the
+ * reference's formats: "" or "yyyy-mm-dd hh24:mi:ss", "yyyy-mm-dd hh24:mi", "yyyy-mm-dd hh24",
+ * "yyyy-mm-dd", "yyyy-mm", "yyyymmddhh24miss", "yyyymmddhh24mi", "yyyymmddhh24", "yyyymmdd",
+ * "hh24miss", "hh24mi", "hh24", "mi"; for any other text the reference leaves the string as it
+ * is, here it is MDC_ERR_ARG.  The reference's localtime_r runs in the process's time zone;
+ * here the zone is one without daylight saving, tz_offset seconds east of UTC (as for
+ * MDC_T_TIME columns, whose values this call turns back into text).  A time whose local year
+ * lies outside 0000..9999 (the reference prints more than four digits, or the year as an
+ * unsigned number) gives MDC_ERR_NUMERIC and unspecified output. */
+int mdc_timetostr_device(int device, const int64_t *d_time, int64_t rows, const char *fmt, int tz_offset,
+                         uint32_t *d_off, uint8_t *d_bytes);
+/* bytes of the text a format gives (19 for the default), or MDC_ERR_ARG for a text that is none
+ * of the formats */
+int mdc_timetostr_width(const char *fmt);
+
 #ifdef __cplusplus
 }
 #endif

@@ -560,6 +560,47 @@ int64_t ORC_FN(format_xml_files)(const char *const *fieldname, const int *fieldl
     return done == nfiles ? nfiles : -1;
 }
 
+/* ---- N4: timetostr ----------------------------------------------------------------------- */
+/* public/_public.cpp:631-722: localtime_r in the process's zone, year + 1900 and month + 1
+ * printed with %04u / %02u in the format's arrangement; the chain of string compares :639-719
+ * as a table of (name, printf format, number of fields, first field). */
+int ORC_FN(timetostr)(int64_t t, const char *fmt, char *out, size_t cap) {
+    time_t tt = (time_t)t;
+    struct tm sttm;
+    memset(&sttm, 0, sizeof sttm);
+    localtime_r(&tt, &sttm);
+    unsigned v[6] = {(unsigned)(sttm.tm_year + 1900), (unsigned)(sttm.tm_mon + 1), (unsigned)sttm.tm_mday,
+                     (unsigned)sttm.tm_hour, (unsigned)sttm.tm_min, (unsigned)sttm.tm_sec};
+    static const struct {
+        const char *name, *pf;
+        int first;
+    } table[] = {
+        {"", "%04u-%02u-%02u %02u:%02u:%02u", 0},
+        {"yyyy-mm-dd hh24:mi:ss", "%04u-%02u-%02u %02u:%02u:%02u", 0},
+        {"yyyy-mm-dd hh24:mi", "%04u-%02u-%02u %02u:%02u", 0},
+        {"yyyy-mm-dd hh24", "%04u-%02u-%02u %02u", 0},
+        {"yyyy-mm-dd", "%04u-%02u-%02u", 0},
+        {"yyyy-mm", "%04u-%02u", 0},
+        {"yyyymmddhh24miss", "%04u%02u%02u%02u%02u%02u", 0},
+        {"yyyymmddhh24mi", "%04u%02u%02u%02u%02u", 0},
+        {"yyyymmddhh24", "%04u%02u%02u%02u", 0},
+        {"yyyymmdd", "%04u%02u%02u", 0},
+        {"hh24miss", "%02u%02u%02u", 3},
+        {"hh24mi", "%02u%02u", 3},
+        {"hh24", "%02u", 3},
+        {"mi", "%02u", 4},
+    };
+    for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i)
+        if (strcmp(fmt, table[i].name) == 0) {
+            unsigned a[6] = {0, 0, 0, 0, 0, 0};
+            for (int k = 0; table[i].first + k < 6; ++k) a[k] = v[table[i].first + k];
+            /* (arguments beyond those the format names are ignored by printf) */
+            int n = snprintf(out, cap, table[i].pf, a[0], a[1], a[2], a[3], a[4], a[5]);
+            return n < 0 ? -1 : n;
+        }
+    return -1;
+}
+
 /* ---- N2: routing, matchstr, SQL text ---------------------------------------------------- */
 
 /* one piece of a splittocmd() result: [p, p+n) */

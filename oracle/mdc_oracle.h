@@ -141,6 +141,11 @@ typedef struct orc_xmltotable {
     char execsql[256];
 } orc_xmltotable;
 
+/* N4  timetostr(ttime,strtime,fmt), public/_public.cpp:631-722, in the process's time zone:
+ * the text into out (cap bytes, NUL-terminated), its length returned; -1 for a text that is
+ * none of the formats (the reference leaves the string as it is) */
+int ORC_FN(timetostr)(int64_t t, const char *fmt, char *out, size_t cap);
+
 /* matchstr(str,rules), public/_public.cpp:213-263: 1 = match */
 int ORC_FN(matchstr)(const char *str, const char *rules);
 

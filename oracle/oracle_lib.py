@@ -122,6 +122,8 @@ class Checker:
         f("format_xml").argtypes = [vp, vp, ci, vp, vp, i64, i64, vp, vp, i64, ctypes.POINTER(i64)]
         f("format_xml_files").restype = i64
         f("format_xml_files").argtypes = [vp, vp, ci, vp, vp, i64, i64] + [ctypes.c_char_p] * 4 + [ci]
+        f("timetostr").restype = ci
+        f("timetostr").argtypes = [i64, ctypes.c_char_p, ctypes.c_char_p, sz]
         f("matchstr").restype = ci
         f("matchstr").argtypes = [ctypes.c_char_p, ctypes.c_char_p]
         f("load_xmltotable").restype = i64
@@ -245,6 +247,14 @@ class Checker:
                                            outpath.encode(), bfilename.encode(), timestamp.encode(),
                                            efilename.encode(), first_seq)
 
+
+    # -- times as text -------------------------------------------------------------------
+    def timetostr(self, t: int, fmt: str = ""):
+        """timetostr(t, fmt) in the process's time zone: the text as bytes, None for a text that is
+        none of the formats."""
+        buf = ctypes.create_string_buffer(64)
+        n = self._f("timetostr")(int(t), fmt.encode(), buf, 64)
+        return None if n < 0 else buf.raw[:n]
 
     # -- routing and SQL text -----------------------------------------------------------
     def matchstr(self, name, rules) -> bool:

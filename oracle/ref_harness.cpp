@@ -395,6 +395,19 @@ int64_t ref_format_xml(const char *const *fieldname, const int *fieldlen, int nf
     return (int64_t)pos;
 }
 
+/* N4.  The reference's timetostr as it is; a format it does not know leaves the string
+ * untouched, which a marker in the string shows. */
+int ref_timetostr(int64_t t, const char *fmt, char *out, size_t cap) {
+    std::string s = "\x01";
+    timetostr((time_t)t, s, fmt);
+    if (s == "\x01") return -1;
+    if (cap == 0) return -1;
+    size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+    memcpy(out, s.data(), n);
+    out[n] = 0;
+    return (int)s.size();
+}
+
 /* N2.  matchstr is the reference's own.  loadxmltotable, crtsql and preparesql live in
  * tools/xmltodb.cpp (needs OCI): their loops are restated here around the reference's own
  * cifile::readline, getxmlbuffer (char* and int forms), sformat and deleterchr. */
