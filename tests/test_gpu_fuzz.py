@@ -2,6 +2,7 @@
 other end marks, over inputs from fully regular (every tile follows the tag template) to heavily
 damaged (every tile takes the table lookup), several tiles each.  Bit-exact against the CPU
 checker."""
+import os
 import random
 
 import numpy as np
@@ -38,7 +39,7 @@ def resolve(cols, typed):
     return [d[i] if t < 0 else t for i, t in enumerate(typed)]
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MDC_FUZZ_SEEDS", "24"))))  # (more seeds for a longer hunt)
 def test_random_schema(port, seed):
     rng = random.Random(1000 + seed)
     cols, typed = random_schema(rng)
@@ -89,3 +90,56 @@ def test_sample_record_around_the_template_window(port, first):
     got = p.parse_host(data).to_host()
     p.close()
     assert_batches_equal(got, port.parse_xml(data, cases.SMALL), f"first {first}")
+
+
+def random_lines(rng, nlines, sep: bytes, nfields, regular):
+    """Delimited lines: `regular` of them well-formed numbers of the usual lengths (waves of plain
+    cells), the others from fuzz_csv's mixture."""
+    odd = [b"", b" ", b"  x  ", b"1e5", b"TRUE", b" true", b"a b", b" b ", b"99999999999999999999", b"4000000000",
+           b"\r", b"x\x00y", b"1.2.3", b"-", b"+", b".", b"-.5", b"12345678", b"123456789", b"-1234567", b"1234567.", b"0000000.1"]
+    out = bytearray()
+    for _ in range(nlines):
+        if rng.random() < regular:
+            fields = []
+            for _ in range(nfields):
+                k = rng.random()
+                if k < 0.4:
+                    fields.append(b"%d" % rng.randint(-999, 99999))
+                elif k < 0.8:
+                    fields.append(b"%.*f" % (rng.randint(1, 3), rng.uniform(-50, 1100)))
+                elif k < 0.9:
+                    fields.append(b"2024%02d%02d%02d%02d%02d" % (rng.randint(1, 12), rng.randint(1, 28), rng.randint(0, 23),
+                                                                 rng.randint(0, 59), rng.randint(0, 59)))
+                else:
+                    fields.append(b"%d" % rng.randint(0, 10 ** rng.randint(1, 17)))
+        else:
+            k = rng.choice([0, 1, nfields - 1, nfields, nfields, nfields + 1, nfields + 3])
+            fields = [rng.choice(odd) if rng.random() < 0.5 else bytes(rng.choice(b"0123456789.-+ abT") for _ in range(rng.randrange(0, 20)))
+                      for _ in range(k)]
+        out += sep.join(fields) + b"\n"
+    if rng.random() < 0.5:
+        out += b"unterminated" + sep + b"tail"
+    return bytes(out)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MDC_FUZZ_SEEDS", "24"))))
+def test_random_delimited(port, seed):
+    """Random separators (one byte: the parallel split; more: the serial walk), field counts, clips,
+    conversions and trimming over lines from all well-formed to all odd."""
+    rng = random.Random(7000 + seed)
+    sep = rng.choice([",", ",", ";", "|", " ", "\t", "~!~", "::", "ab"])
+    nfields = rng.choice([1, 2, 3, 6, 10, 10, 17, 40])
+    ilen = [rng.choice([0, 0, 0, 1, 3, 8, 9, 16, 17, 30]) for _ in range(nfields)]
+    typed = [rng.choice([0, 0, 1, 2, 3, 4, 5, 5, 6, 7]) for _ in range(nfields)]
+    bdel = rng.random() < 0.4
+    regular = rng.choice([1.0, 1.0, 0.98, 0.7, 0.0])
+    nlines = rng.choice([50, 500, 5000])
+    data = random_lines(rng, nlines, sep.encode(), nfields, regular)
+    print("seed", seed, "sep", repr(sep), "fields", nfields, "bdelspace", bdel, "regular", regular, "bytes", len(data), flush=True)
+    exp = port.parse_csv(data, sep, nfields, ilen=ilen, typed=typed, bdelspace=bdel)
+    p = capi.Parser.csv(sep, nfields, ilen=ilen, typed=typed, bdelspace=bdel)
+    try:
+        got = p.parse_host(np.frombuffer(data, dtype=np.uint8)).to_host()
+        assert_batches_equal(got, exp, f"seed {seed}")
+    finally:
+        p.close()
