@@ -30,7 +30,7 @@ hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t strea
 hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream);
 hipError_t launch_template_kernel(const TileParams &P, hipStream_t stream);
 uint32_t scan_segments(uint32_t ntiles);
-hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt,
+hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt, uint64_t *report,
                              hipStream_t stream);
 hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_t *const *bytes,
                              uint64_t *const *val, uint32_t *valid, const uint32_t *found, uint64_t rows,
@@ -73,6 +73,11 @@ static int fail(int code, const char *fmt, ...) {
 // ------------------------------------------------------------------------------------------
 // devices and a caching device allocator (hipMalloc of GB-sized buffers costs milliseconds;
 // a daemon parses file after file of the same shape)
+
+// d_status: two status words, the diagnostic builds' counters from byte 16 on, and from u64
+// index REPORT_TOTALS on the totals that the scan writes for the host
+static const size_t REPORT_TOTALS = 32;
+static const size_t STATUS_BYTES = (REPORT_TOTALS + MAX_COLS + 8) * 8;
 
 struct Device {
     int id = -1;
@@ -184,7 +189,11 @@ struct mdc_parser {
     size_t map_cap = 0, map_stride = 0;
     double rows_per_byte = 0;       // of the previous parse; sizes the cell map
     size_t ws_tiles = 0;
-    uint64_t *h_totals = nullptr;  // pinned: ncols+1 totals + status
+    // pinned: h_report mirrors the head of d_status (status words, then from REPORT_TOTALS on the
+    // ncols+1 totals, where h_totals points); behind it the batch's pointer table on its way to the device
+    uint64_t *h_report = nullptr;
+    uint64_t *h_totals = nullptr;
+    void **h_ptrs = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     mdc_timing timing{};
 };
@@ -474,15 +483,18 @@ static int parser_finish(mdc_parser *p, const mdc_opts *opts) {
     if (rc) return rc;
     HIP_TRY(hipMemcpy(p->d_blob, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
     void *st = nullptr;
-    rc = dev_alloc(p->dev, 256, &st);
+    rc = dev_alloc(p->dev, STATUS_BYTES, &st);
     if (rc) return rc;
     p->d_status = (uint32_t *)st;
-    HIP_TRY(hipMemset(p->d_status, 0, 256));
+    HIP_TRY(hipMemset(p->d_status, 0, STATUS_BYTES));
     rc = dev_alloc(p->dev, (1 + TMPL_MAX) * 16 + MAX_COLS * 8 + 16, &st);
     if (rc) return rc;
     p->d_tmpl = (uint32_t *)st;
     HIP_TRY(hipMemset(p->d_tmpl, 0, (1 + TMPL_MAX) * 16 + MAX_COLS * 8 + 16));
-    HIP_TRY(hipHostMalloc((void **)&p->h_totals, (MAX_COLS + 8) * sizeof(uint64_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&p->h_report, (REPORT_TOTALS + MAX_COLS + 8 + 3 * MAX_COLS) * sizeof(uint64_t),
+                          hipHostMallocDefault));
+    p->h_totals = p->h_report + REPORT_TOTALS;
+    p->h_ptrs = (void **)(p->h_totals + MAX_COLS + 8);
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&p->ev[i]));
     return MDC_OK;
 }
@@ -554,7 +566,7 @@ extern "C" void mdc_parser_destroy(mdc_parser *p) {
         dev_free(p->dev, p->d_tmpl);
         dev_free(p->dev, p->d_hdr);
         dev_free(p->dev, p->d_cellmap);
-        if (p->h_totals) (void)hipHostFree(p->h_totals);
+        if (p->h_report) (void)hipHostFree(p->h_report);
         for (int i = 0; i < 4; ++i)
             if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
     }
@@ -703,26 +715,26 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
         if (build_tmpl) HIP_TRY(launch_template_kernel(P, s));
         HIP_TRY(launch_tile_kernel(false, P, s));
         HIP_TRY(hipEventRecord(p->ev[1], s));
-        HIP_TRY(launch_scan_tiles(p->d_counts, p->d_base, (uint32_t)ntiles, ncnt, s));
+        HIP_TRY(launch_scan_tiles(p->d_counts, p->d_base, (uint32_t)ntiles, ncnt, (uint64_t *)p->d_status + REPORT_TOTALS, s));
         HIP_TRY(hipEventRecord(p->ev[2], s));
-        HIP_TRY(hipMemcpyAsync(p->h_totals, p->d_base + ntiles * ncnt, ncnt * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(p->h_totals + ncnt, p->d_status, 8, hipMemcpyDeviceToHost, s));
+        // status words and totals with one copy
+        HIP_TRY(hipMemcpyAsync(p->h_report, p->d_status, (REPORT_TOTALS + ncnt) * 8, hipMemcpyDeviceToHost, s));
         if (build_tmpl) HIP_TRY(hipMemcpyAsync(p->h_totals + ncnt + 1, p->d_tmpl, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (P.use_tmpl && ntiles) {
             // keep a template that exists and that most tiles followed
-            const uint64_t left = p->h_totals[ncnt] >> 32;
+            const uint64_t left = p->h_report[0] >> 32;
             if (build_tmpl) p->tmpl_valid = (uint32_t)p->h_totals[ncnt + 1] != 0;
             if (left * 8 > ntiles) p->tmpl_valid = false;
         }
-        if (((uint32_t)p->h_totals[ncnt] & ST_RECORD_TOO_LONG) && p->lb_level < 2) {
+        if (((uint32_t)p->h_report[0] & ST_RECORD_TOO_LONG) && p->lb_level < 2) {
             ++p->lb_level;
             continue;
         }
         break;
     }
-    const bool unmapped = ((uint32_t)p->h_totals[ncnt] & ST_UNMAPPED) != 0;
-    rc = status_to_error((uint32_t)p->h_totals[ncnt] & ~(ST_NUMERIC_RANGE | ST_UNMAPPED));
+    const bool unmapped = ((uint32_t)p->h_report[0] & ST_UNMAPPED) != 0;
+    rc = status_to_error((uint32_t)p->h_report[0] & ~(ST_NUMERIC_RANGE | ST_UNMAPPED));
     if (rc) return rc;
     mdc_timing &t = p->timing;
     (void)hipEventElapsedTime(&t.count_ms, p->ev[0], p->ev[1]);
@@ -783,14 +795,14 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     bytes_out += 2 * rows * p->words * 4;
     ALLOC_OR_FAIL(3 * (size_t)ncols * sizeof(void *), b->d_ptrs, void *);
     {
-        std::vector<void *> hp(3 * ncols);
+        // (from pinned memory that lives until the parser's next call: no wait for the copy here)
+        void **hp = p->h_ptrs;
         for (uint32_t c = 0; c < ncols; ++c) {
             hp[c] = b->d_off[c];
             hp[ncols + c] = b->d_bytes[c];
             hp[2 * ncols + c] = b->d_val[c];
         }
-        HIP_TRY(hipMemcpyAsync(b->d_ptrs, hp.data(), hp.size() * sizeof(void *), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));  // hp is a stack object
+        HIP_TRY(hipMemcpyAsync(b->d_ptrs, hp, 3 * (size_t)ncols * sizeof(void *), hipMemcpyHostToDevice, s));
     }
     if (ntiles == 0) {
         // nothing to launch: every offset array is the single entry 0
@@ -817,13 +829,13 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
         return fail(MDC_ERR_HIP, "launch: %s", hipGetErrorString(le));
     }
     HIP_TRY(hipEventRecord(p->ev[3], s));
-    HIP_TRY(hipMemcpyAsync(p->h_totals + ncnt, p->d_status, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(p->h_report, p->d_status, 4, hipMemcpyDeviceToHost, s));
     hipError_t se = hipStreamSynchronize(s);
     if (se != hipSuccess) {
         batch_release(b);
         return fail(MDC_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(se));
     }
-    uint32_t st = (uint32_t)p->h_totals[ncnt] & ~ST_UNMAPPED;
+    uint32_t st = (uint32_t)p->h_report[0] & ~ST_UNMAPPED;
     if (st & ST_NUMERIC_RANGE) {
         // some floating-point texts need the multi-precision stage
         le = launch_long_float((const uint8_t *)p->d_blob, P.off, P.bytes, P.val, b->d_valid, b->d_found, rows, ncols,

@@ -2172,7 +2172,7 @@ __global__ __launch_bounds__(1024) void scan_local_kernel(const uint32_t *counts
 }
 
 __global__ __launch_bounds__(1024) void scan_add_kernel(uint64_t *base, const uint64_t *segtot, uint32_t ntiles,
-                                                        uint32_t ncnt) {
+                                                        uint32_t ncnt, uint64_t *report) {
     __shared__ uint64_t wtot[16];
     const uint32_t seg = blockIdx.x, j = blockIdx.y;
     uint64_t part = 0;
@@ -2184,7 +2184,11 @@ __global__ __launch_bounds__(1024) void scan_add_kernel(uint64_t *base, const ui
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (t0 + i < ntiles) base[(uint64_t)(t0 + i) * ncnt + j] += pre;
-    if (seg == gridDim.x - 1 && threadIdx.x == 0) base[(uint64_t)ntiles * ncnt + j] = pre + segtot[(uint64_t)seg * ncnt + j];
+    if (seg == gridDim.x - 1 && threadIdx.x == 0) {
+        const uint64_t tot = pre + segtot[(uint64_t)seg * ncnt + j];
+        base[(uint64_t)ntiles * ncnt + j] = tot;
+        if (report) report[j] = tot;  // (beside the status words: the host fetches both with one copy)
+    }
 }
 
 // Expands a compact column into fixed-stride NUL-terminated slots (the array-bind layout).
@@ -2293,12 +2297,13 @@ hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t strea
 // base holds (ntiles + 1 + segments) rows of ncnt counters: prefixes, totals, segment totals
 uint32_t scan_segments(uint32_t ntiles) { return ntiles ? (ntiles + SCAN_SEG - 1) / SCAN_SEG : 1; }
 
-hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt,
+hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt, uint64_t *report,
                              hipStream_t stream) {
     const uint32_t nseg = scan_segments(ntiles);
     uint64_t *segtot = base + (uint64_t)(ntiles + 1) * ncnt;
     hipLaunchKernelGGL(scan_local_kernel, dim3(nseg, ncnt), dim3(1024), 0, stream, counts, base, segtot, ntiles, ncnt);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(nseg, ncnt), dim3(1024), 0, stream, base, segtot, ntiles, ncnt);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(nseg, ncnt), dim3(1024), 0, stream, base, segtot, ntiles, ncnt,
+                       report);
     return hipGetLastError();
 }
 
