@@ -25,8 +25,11 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 // record whose events all repeat the sample's tag texts byte for byte matches what sample event
 // k matched, so such a record needs no table lookup.  In memory: 4 words of header (word 0 =
 // number of events, 0 = no template), then one 4-word entry per event: the first 8 bytes of the
-// tag text through '>' (zero beyond it), bytes 8..11, and length | pattern index << 8
-// (TMPL_NOPAT: the sample's event matched no pattern).
+// tag text through '>' (zero beyond it), bytes 8..11, and a word of two shift counts and the
+// pattern: 64 - 8 x (text bytes among the first 8) | (32 - 8 x (text bytes among bytes 8..11)) << 8
+// | pattern index << 16 (TMPL_NOPAT: the sample's event matched no pattern).  A 64-bit shift to
+// the left by a count leaves the text's bytes of a window, and nothing of the second word when the
+// text ends before it.
 // Behind the TMPL_MAX entries: the column plan, two words per column, for records that follow the
 // template: source column of the cell (itself, or the nearest earlier column whose tags the sample
 // has, when values carry over) | filter level << 8 | found << 10 | has a source << 11 |
@@ -34,7 +37,7 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr uint32_t TMPL_MAX = 64;
 constexpr uint32_t TMPL_PLAN_WORD = 4 + 4 * 64;  // word index of the plan (= 4 + 4 * TMPL_MAX)
 constexpr uint32_t TMPL_MAXLEN = 12;
-constexpr uint32_t TMPL_NOPAT = 0xFFFFFFu;
+constexpr uint32_t TMPL_NOPAT = 0xFFFFu;
 constexpr uint32_t TMPL_WINDOW = 4096;  // the sample record is the second record of the input and must end in this window
 
 static_assert(TILE == BLOCK * 64, "every lane owns 64 tile bytes");

@@ -417,12 +417,12 @@ __device__ __forceinline__ bool tmpl_event(const uint8_t *sdata, const uint4 *tl
     uint32_t w0, w1, w2;
     lds_bytes12(sdata + q + 1, w0, w1, w2);
     const uint64_t w = (uint64_t)w0 | ((uint64_t)w1 << 32);
-    const uint32_t L = t.w & 0xFFu, idx = t.w >> 8;  // 1 <= L <= TMPL_MAXLEN
-    const uint32_t n1 = L < 8 ? L : 8;
-    const uint64_t m1 = ~0ull >> (64 - 8 * n1);
-    const uint32_t m2 = L > 8 ? 0xFFFFFFFFu >> (32 - 8 * (L - 8)) : 0u;
+    // the bytes that do not belong to the text are shifted out (the shift counts come with the entry)
+    const uint32_t sh1 = t.w & 0xFFu, sh2 = (t.w >> 8) & 0xFFu, idx = t.w >> 16;
     const uint64_t key = (uint64_t)t.x | ((uint64_t)t.y << 32);
-    const bool ok = (((w ^ key) & m1) == 0) & (((w2 ^ t.z) & m2) == 0);
+    const uint64_t d1 = (w ^ key) << sh1;
+    const uint32_t d2 = (uint32_t)((uint64_t)(w2 ^ t.z) << sh2);
+    const bool ok = (d1 == 0) & (d2 == 0);
     if (ok && idx != TMPL_NOPAT) ((uint16_t *)evt)[idx * RB + rl] = (uint16_t)q;
     return ok;
 }
@@ -556,7 +556,9 @@ __global__ __launch_bounds__(64) void template_kernel(const TileParams P) {
         e[0] = w[0];
         e[1] = w[1];
         e[2] = w[2];
-        e[3] = L | (idx << 8);
+        // shift counts that leave the text's bytes only: of the first 8 bytes, of bytes 8..11
+        const uint32_t sh1 = 64 - 8 * (L < 8 ? L : 8), sh2 = L > 8 ? 32 - 8 * (L - 8) : 32;
+        e[3] = sh1 | (sh2 << 8) | (idx << 16);
         ++k;
     }
     __syncthreads();
