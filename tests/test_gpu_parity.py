@@ -1,5 +1,7 @@
 """GPU parity: the HIP path, called through the C ABI, against the CPU checker and the golden
 vectors.  Bit-exact for every output (cell bytes, offsets, record offsets, masks, typed values)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -432,7 +434,7 @@ def test_full_size_batch_equals_its_parts(port):
     head equals the CPU checker; rows match the generator's count."""
     from dsp_amd import shard
 
-    data, n = gen.mind_xml(nbytes=1 << 30)
+    data, n = gen.mind_xml(nbytes=int(os.environ.get("MDC_FULL_BYTES", 1 << 30)))  # (a larger batch on request)
     p = capi.Parser.xml(schema.ZHOBTMIND)
     whole_b = p.parse_host(data)
     assert whole_b.rows == n
