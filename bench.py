@@ -104,6 +104,47 @@ def cpu_baseline_all_cores(workload, procs):
     }
 
 
+def copy_ceiling(device, src_ptr, nbytes, repeats=10):
+    """A measured ceiling beside the data-sheet peak: device-to-device hipMemcpy of the input
+    batch (one byte read and one written per byte, the mix closest to the write kernel's), timed
+    with HIP events on the null stream; GB/s read + written.  None when the runtime library cannot
+    be reached from here."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        return None
+    vp = ctypes.c_void_p
+    dst = vp()
+    if capi.lib().mdc_device_alloc(device, nbytes, ctypes.byref(dst)) != 0:
+        return None
+    try:
+        hip.hipMemcpyAsync.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_int, vp]
+        hip.hipEventRecord.argtypes = [vp, vp]
+        hip.hipEventSynchronize.argtypes = [vp]
+        hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), vp, vp]
+        hip.hipEventDestroy.argtypes = [vp]
+        e0, e1 = vp(), vp()
+        if hip.hipSetDevice(device) or hip.hipEventCreate(ctypes.byref(e0)) or hip.hipEventCreate(ctypes.byref(e1)):
+            return None
+        best = None
+        for _ in range(repeats):
+            rc = hip.hipEventRecord(e0, None)
+            rc |= hip.hipMemcpyAsync(dst, vp(src_ptr), nbytes, 3, None)  # 3 = hipMemcpyDeviceToDevice
+            rc |= hip.hipEventRecord(e1, None)
+            rc |= hip.hipEventSynchronize(e1)
+            ms = ctypes.c_float()
+            rc |= hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1)
+            if rc:
+                return None
+            best = ms.value if best is None else min(best, ms.value)
+        hip.hipEventDestroy(e0)
+        hip.hipEventDestroy(e1)
+        return round(2.0 * nbytes / (best * 1e-3) / 1e9, 1)
+    finally:
+        capi.lib().mdc_device_free(device, dst)
+
+
 def measured_traffic(kernel, nbytes):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE and
     WRITE_SIZE need separate profiler runs, so they cannot be taken inside this process); only
@@ -213,6 +254,11 @@ def main():
                           "write_pass": round(write_ms, 4), "device_total": round(acc["total"] / k, 4)},
             "hbm_frac_whole_parse": round(alg_bytes / (acc["total"] / k * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
         }
+        if world == 1:
+            ceiling = copy_ceiling(device, dbuf.ptr, dbuf.n)
+            if ceiling:
+                out["roofline"]["measured_copy_GBps"] = ceiling  # hipMemcpy device to device, read + written
+                out["roofline"]["frac_of_measured_copy"] = round(achieved / ceiling, 4)
         if a.verify:
             from oracle import oracle_lib
             chk = oracle_lib.load("port")
