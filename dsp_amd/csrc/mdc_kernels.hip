@@ -1747,12 +1747,15 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                     // without a per-lane branch: source from the column plan, 16 bytes of it, digit
                     // mask.  The date level keeps the digits, text keeps everything, and so does a
                     // number that has only a sign in front and one point besides its digits.
-                    const uint2 pl = plan_l[c];
+                    uint2 pl = plan_l[c];
+                    uint32_t re = recend[r + 1];
+                    // (both words of the plan and the record's end are fetched here, not behind the
+                    // branches the compiler would make of the selects below)
+                    asm volatile("" : "+v"(pl.x), "+v"(pl.y), "+v"(re));
                     const uint32_t cs = pl.x & 0xFFu, nml2 = pl.x >> 16;
                     const int cl = (int)pl.y;
                     const uint32_t lvl = (pl.x >> 8) & 3u;
                     const uint32_t o = ((const uint16_t *)evt)[(2 * cs) * RB + r], e = ((const uint16_t *)evt)[(2 * cs + 1) * RB + r];
-                    const uint32_t re = recend[r + 1];
                     // (a source column's tags are there in every record that follows the template;
                     // the test on the positions only keeps a length in bounds whatever happens)
                     const bool have = ((pl.x >> 11) & 1u) & act & (o != NONE16) & (e != NONE16);
