@@ -757,6 +757,33 @@ __device__ __forceinline__ uint32_t parse4(uint32_t w) {
     return __umul24(__builtin_amdgcn_udot4(d, 0x0000010Au, 0u, false), 100u) + __builtin_amdgcn_udot4(d, 0x010A0000u, 0u, false);
 }
 
+// strtotime's value (see time_convert) of fourteen digits that lie right-aligned in the 16-byte
+// pair (ylo, yhi): two zero bytes, then yyyymmddhhmiss.  Without a branch or a table: the month
+// is folded with a multiplication for the division by 12, the days before it come from
+// floor(275 M / 9) less one or two from March on, and the leap days are counted from a year
+// 400 earlier, which keeps every dividend positive (month 00 of year 0000 is a year -1).
+__device__ __forceinline__ uint64_t time_from_digits(uint64_t ylo, uint64_t yhi, int32_t tz_offset) {
+    const uint32_t w0 = (uint32_t)ylo & 0x0F0F0F0Fu, w1 = (uint32_t)(ylo >> 32) & 0x0F0F0F0Fu;
+    const uint32_t w2 = (uint32_t)yhi & 0x0F0F0F0Fu, w3 = (uint32_t)(yhi >> 32) & 0x0F0F0F0Fu;
+    const uint32_t year = __umul24(__builtin_amdgcn_udot4(w0, 0x010A0000u, 0u, false), 100u) +
+                          __builtin_amdgcn_udot4(w1, 0x0000010Au, 0u, false);
+    const uint32_t mon1 = __builtin_amdgcn_udot4(w1, 0x010A0000u, 0u, false);  // 0..99: mktime's month + 1
+    const uint32_t mday = __builtin_amdgcn_udot4(w2, 0x0000010Au, 0u, false), hour = __builtin_amdgcn_udot4(w2, 0x010A0000u, 0u, false);
+    const uint32_t mi = __builtin_amdgcn_udot4(w3, 0x0000010Au, 0u, false), sec = __builtin_amdgcn_udot4(w3, 0x010A0000u, 0u, false);
+    const uint32_t m12 = mon1 + 11;                          // month + 12, 11..110
+    const uint32_t q = __umul24(m12, 21846u) >> 18;          // m12 / 12
+    const uint32_t M = m12 - 12u * q + 1;                    // month of the year, 1..12
+    const uint32_t Y = year + q + 399;                       // the year (year + q - 1) plus 400
+    const bool leap = ((Y & 3u) == 0) & ((Y % 100u != 0) | (Y % 400u == 0));
+    const uint32_t t9 = __umul24(275u * M, 7282u) >> 16;     // 275 M / 9
+    const int32_t yday = (int32_t)t9 - (M >= 3 ? (leap ? 1 : 2) : 0) + (int32_t)mday - 31;
+    const uint32_t u = Y - 1;
+    const int32_t leaps = (int32_t)(u / 4 - u / 100 + u / 400) - 97 - 477;  // leap days from 1970 to the year
+    const int32_t days = 365 * ((int32_t)Y - 400 - 1970) + leaps + yday;
+    const int32_t secs = (int32_t)(hour * 3600 + mi * 60 + sec) - tz_offset;
+    return (uint64_t)((int64_t)days * 86400 + secs);
+}
+
 // Returns false when the cell needs the general path.  On success: flen = cell length, (elo,
 // ehi) = the cell's bytes (window with the filtered-out bytes removed), and for typed != NONE
 // the converted value / validity.  D16 = digit bits of the window's bytes.
@@ -875,10 +902,10 @@ __device__ __forceinline__ bool cell_fast(uint64_t lo, uint64_t hi, uint32_t len
 // runs the general code otherwise.  `typed` is the same for the whole wave.
 // SHORT: every cell of the wave has at most 8 source bytes (most numbers): half the window, half
 // the work.
-template <bool SHORT>
+template <bool SHORT, bool TIME = false>
 __device__ __forceinline__ bool cell_simple(const uint4 &w4, uint32_t len, uint32_t lvl, uint32_t typed, bool convert,
-                                            const double *p10, uint32_t &flen, uint64_t &elo, uint64_t &ehi,
-                                            uint64_t &value, bool &valid) {
+                                            const double *p10, int32_t tz_offset, uint32_t &flen, uint64_t &elo,
+                                            uint64_t &ehi, uint64_t &value, bool &valid) {
     constexpr uint32_t CAP = SHORT ? 8 : 16;
     const uint64_t lo = (uint64_t)w4.x | ((uint64_t)w4.y << 32);
     const uint64_t hi = SHORT ? 0ull : (uint64_t)w4.z | ((uint64_t)w4.w << 32);
@@ -918,6 +945,7 @@ __device__ __forceinline__ bool cell_simple(const uint4 &w4, uint32_t len, uint3
     const uint64_t zlo = xlo & ~(uint64_t)(0xFFu & (0u - sg));
     uint64_t m;
     uint32_t m32 = 0;
+    uint64_t tval = 0;
     if (SHORT) {
         const uint32_t sh = 8 * (8 - nd - sg);
         const uint64_t y = (sh & 64) ? 0ull : zlo << sh;
@@ -932,6 +960,12 @@ __device__ __forceinline__ bool cell_simple(const uint4 &w4, uint32_t len, uint3
         const uint32_t hi8 = __umul24(parse4((uint32_t)ylo), 10000u) + parse4((uint32_t)(ylo >> 32));
         const uint32_t lo8 = __umul24(parse4((uint32_t)yhi), 10000u) + parse4((uint32_t)(yhi >> 32));
         m = (uint64_t)hi8 * 100000000ull + lo8;
+        if (TIME) tval = time_from_digits(ylo, yhi, tz_offset);
+    }
+    if (TIME) {  // fourteen digits, whatever else the text holds
+        valid = (nd == 14) & convert;
+        value = valid ? tval : 0;
+        return simple;
     }
     const bool issigned = (typed == T_I32) | (typed == T_I64) | (typed == T_F64);
     const bool neg = keep & issigned & (sg != 0) & (c0 == '-');
@@ -1007,6 +1041,7 @@ struct CellEnv {
     const uint8_t *sdata;  // LDS image of the tile and its look-behind
     bool has_nul, nulcut;
     const double *p10;
+    int32_t tz_offset = 0;  // time columns: seconds east of UTC
     uint32_t W;
     uint32_t *vmask;
     uint8_t *wstage;  // this wave's staging area for cell bytes
@@ -1062,7 +1097,7 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
         // a whole pass of plain cells takes the straight-line path
         bool plain = false;
         if (WRITE && E.plain_ok) {
-            uint32_t tyu = (typed == T_F32 || typed == T_BOOL || typed == T_TIME) ? (uint32_t)T_NONE : typed;
+            uint32_t tyu = (typed == T_F32 || typed == T_BOOL) ? (uint32_t)T_NONE : typed;
 #ifdef MDC_ABLATE
             if (E.dbg & 64) tyu = T_NONE;
 #endif
@@ -1071,9 +1106,12 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
             const uint4 w4 = lds_u128(sdata + cs_[ps]);  // (a lane without a record reads the image's first bytes)
             const uint32_t lenp = act ? cl_[ps] : 0u;
             const bool conv = tyu != T_NONE && (fd_[ps] || E.nulcut);
-            const bool sc = __builtin_amdgcn_ballot_w64(lenp > 8) == 0
-                                ? cell_simple<true>(w4, lenp, cv_[ps], tyu, conv, E.p10, flen, elo, ehi, value, valid)
-                                : cell_simple<false>(w4, lenp, cv_[ps], tyu, conv, E.p10, flen, elo, ehi, value, valid);
+            // (a time column has an instance of its own: the other types' code stays as it is)
+            const bool sc = tyu == T_TIME
+                                ? cell_simple<false, true>(w4, lenp, cv_[ps], tyu, conv, E.p10, E.tz_offset, flen, elo, ehi, value, valid)
+                            : __builtin_amdgcn_ballot_w64(lenp > 8) == 0
+                                ? cell_simple<true>(w4, lenp, cv_[ps], tyu, conv, E.p10, E.tz_offset, flen, elo, ehi, value, valid)
+                                : cell_simple<false>(w4, lenp, cv_[ps], tyu, conv, E.p10, E.tz_offset, flen, elo, ehi, value, valid);
             plain = __builtin_amdgcn_ballot_w64(!sc) == 0 && (typed == tyu || typed == T_NONE);
             if (plain) {
                 fast = true;
@@ -1345,13 +1383,15 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         for (int k = 0; k < 4; ++k) v[k] = ((const uint4 *)sdata)[my_li / CHUNK + k];
         uint64_t nlm = mask64_eq(v, 0x0A0A0A0Au);
         em = !csv ? mask64_eq(v, 0x3C3C3C3Cu) : sepfast ? mask64_eq(v, rep4(H->sep[0])) : 0;
-        if (any_zero64(v)) ms[MS_HASNUL] = 1;
+        bool nul = any_zero64(v);
         const int lim = te_li - my_li;  // bytes of this lane that belong to the input
         if (lim < 64) {
             const uint64_t keep = lim <= 0 ? 0 : (~0ull >> (64 - lim));
             nlm &= keep;
             em &= keep;
+            nul = (mask64_eq(v, 0u) & keep) != 0;  // (the zeros behind the input's end are not the input's)
         }
+        if (nul) ms[MS_HASNUL] = 1;
         while (nlm) {
             const int b = __builtin_ctzll(nlm);
             nlm &= nlm - 1;
@@ -1675,6 +1715,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         E.has_nul = has_nul;
         E.nulcut = nulcut;
         E.p10 = p10;
+        E.tz_offset = H->tz_offset;
         E.W = W;
         E.vmask = vmask;
         E.wstage = stage + wave * (L.stage_cap / (BLOCK / 64));
@@ -2074,6 +2115,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     E.has_nul = has_nul;
     E.nulcut = H->carry != 0 && H->mode != MODE_CSV;
     E.p10 = (const double *)(smem + L.schema + sch_head);
+    E.tz_offset = H->tz_offset;
     E.W = W;
     E.vmask = vmask;
     E.wstage = stage + wave * (L.stage_cap / (BLOCK / 64));

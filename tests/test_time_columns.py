@@ -145,3 +145,45 @@ def test_typed_code_is_accepted_without_a_gpu():
     with pytest.raises(capi.MdcError) as e:
         capi.Parser.xml(COLS, typed=TYPED, tz_offset=28800)
     assert e.value.code == capi.MDC_ERR_NO_DEVICE  # (not MDC_ERR_ARG: the schema itself passed)
+
+
+def compact_file(seed, n):
+    """Records whose time cells are all short and plain (fourteen digits, some with a sign in front
+    or a point inside, some with fewer digits), so that whole waves of them take the write pass's
+    straight-line conversion; every field value from 00 to 99 occurs."""
+    rng = random.Random(seed)
+    recs = []
+    for i in range(n):
+        k = rng.random()
+        if k < 0.5:
+            t = "%04d%02d%02d%02d%02d%02d" % (rng.randint(0, 9999), rng.randint(0, 99), rng.randint(0, 99), rng.randint(0, 99),
+                                              rng.randint(0, 99), rng.randint(0, 99))
+        elif k < 0.9:
+            t = "%04d%02d%02d%02d%02d%02d" % (rng.randint(1900, 2100), rng.randint(1, 12), rng.randint(1, 31), rng.randint(0, 23),
+                                              rng.randint(0, 59), rng.randint(0, 59))
+        else:
+            t = "".join(rng.choice("0123456789") for _ in range(rng.choice([0, 1, 7, 8, 13, 15, 16])))
+        u = t
+        if rng.random() < 0.3 and 0 < len(t) <= 14:
+            p = rng.randrange(len(t) + 1)
+            u = rng.choice(["", "-", "+"]) + t[:p] + "." + t[p:]
+        recs.append(b"<obtid>%d</obtid><ddatetime>%s</ddatetime><upttime>%s</upttime><note>%s</note><endl/>\n"
+                    % (50000 + i, t.encode(), u.encode()[:16], u.encode()[:16]))
+    return np.frombuffer(b"<data>\n" + b"".join(recs) + b"</data>\n", dtype=np.uint8)
+
+
+# upttime as a number column (sign and point stay in the text), note as text
+COLS_PLAIN = [Col("obtid", "char", 10), Col("ddatetime", "date", 14), Col("upttime", "number", 22), Col("note", "char", 30)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("zone", ZONES, indirect=True, ids=[z[0] for z in ZONES])
+def test_gpu_plain_time_cells(zone, port):
+    from util import assert_batches_equal
+    data = compact_file(31, 20000)
+    exp = port.parse_xml(data, COLS_PLAIN, typed=TYPED)
+    p = capi.Parser.xml(COLS_PLAIN, typed=TYPED, tz_offset=zone[1])
+    got = p.parse_host(data).to_host()
+    p.close()
+    assert_batches_equal(got, exp, zone[0])
+    assert int(np.count_nonzero((exp.valid[:, 0] >> 1) & 1)) > 17000
