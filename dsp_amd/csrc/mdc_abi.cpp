@@ -696,6 +696,8 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     P.tile_hdr = p->d_hdr;
     P.tmpl = p->d_tmpl;
     P.use_tmpl = p->mode == MODE_XML ? 1u : 0u;
+    for (int t : p->typed)
+        if (t == MDC_T_TIME || t == MDC_T_F32) P.special_cols = 1;
 #ifdef MDC_ABLATE
     if (getenv("MDC_NO_TEMPLATE")) P.use_tmpl = 0;
     if (const char *dbg = getenv("MDC_DEBUG_SKIP"))

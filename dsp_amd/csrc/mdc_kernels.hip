@@ -902,7 +902,7 @@ __device__ __forceinline__ bool cell_fast(uint64_t lo, uint64_t hi, uint32_t len
 // runs the general code otherwise.  `typed` is the same for the whole wave.
 // SHORT: every cell of the wave has at most 8 source bytes (most numbers): half the window, half
 // the work.
-template <bool SHORT, bool TIME = false>
+template <bool SHORT, bool TIME = false, bool F32 = false>
 __device__ __forceinline__ bool cell_simple(const uint4 &w4, uint32_t len, uint32_t lvl, uint32_t typed, bool convert,
                                             const double *p10, int32_t tz_offset, uint32_t &flen, uint64_t &elo,
                                             uint64_t &ehi, uint64_t &value, bool &valid) {
@@ -923,7 +923,7 @@ __device__ __forceinline__ bool cell_simple(const uint4 &w4, uint32_t len, uint3
     const uint32_t nd = (uint32_t)__builtin_popcount(D);
     const bool isdate = lvl == LVL_DATE;
     bool simple = (len <= CAP) & ((N1 & (N1 - 1)) == 0) & ((N1 == 0) | (cp == '.')) & !(isdate & (sg != 0));
-    if (!SHORT && typed == T_F64) simple &= nd <= 15;  // (more digits may pass 2^53: the second stage divides exactly)
+    if (!SHORT && (F32 || typed == T_F64)) simple &= nd <= 15;  // (more digits may pass 2^53: the second stage divides exactly)
     if (typed == T_NONE) simple |= (lvl == LVL_CHAR) & (len <= CAP);
     // the window without the decimal point (p == CAP: as it is)
     const uint64_t slo = SHORT ? lo >> 8 : (lo >> 8) | (hi << 56), shi = hi >> 8;
@@ -966,6 +966,18 @@ __device__ __forceinline__ bool cell_simple(const uint4 &w4, uint32_t len, uint3
         valid = (nd == 14) & convert;
         value = valid ? tval : 0;
         return simple;
+    }
+    if (F32) {
+        // binary32: the quotient rounded to binary64 and that to binary32 is the decimal rounded
+        // once, unless the binary64 value lies exactly half way between two binary32 values (then
+        // the first rounding may have hidden on which side the decimal lies: second stage)
+        const bool neg32 = keep & (sg != 0) & (c0 == '-');
+        const uint32_t k10 = keep ? (uint32_t)__builtin_popcount(D >> (p + 1)) : 0u;
+        const double x = (SHORT ? (double)m32 : (double)m) / p10[k10];
+        const bool half = ((uint32_t)__double_as_longlong(x) & 0x1FFFFFFFu) == 0x10000000u;
+        valid = (nd != 0) & convert;
+        value = valid ? (uint64_t)(__float_as_uint((float)x) | (neg32 ? 0x80000000u : 0u)) : 0;
+        return simple & !half;
     }
     const bool issigned = (typed == T_I32) | (typed == T_I64) | (typed == T_F64);
     const bool neg = keep & issigned & (sg != 0) & (c0 == '-');
@@ -1074,7 +1086,9 @@ struct ColOut {
 // and, when WRITE, stores values, end offsets and the filtered bytes (staged in LDS, then
 // 16-byte stores).  gb = global byte position of the batch's first cell in the column arena,
 // rowbase = global row of the batch's first record.  Returns the column's bytes in this batch.
-template <bool WRITE>
+// SPECIAL: the straight-line path also converts time and binary32 columns (instances of their
+// own; a kernel for schemas without such columns does not carry their code).
+template <bool WRITE, bool SPECIAL>
 __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut &O, uint32_t c, uint32_t typed,
                                                  int lane, uint32_t RBn, uint64_t rowbase, uint64_t gb,
                                                  const uint32_t (&cs_)[RB_PASSES], const uint32_t (&cl_)[RB_PASSES],
@@ -1097,7 +1111,7 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
         // a whole pass of plain cells takes the straight-line path
         bool plain = false;
         if (WRITE && E.plain_ok) {
-            uint32_t tyu = (typed == T_F32 || typed == T_BOOL) ? (uint32_t)T_NONE : typed;
+            uint32_t tyu = (typed == T_BOOL || (!SPECIAL && (typed == T_F32 || typed == T_TIME))) ? (uint32_t)T_NONE : typed;
 #ifdef MDC_ABLATE
             if (E.dbg & 64) tyu = T_NONE;
 #endif
@@ -1107,8 +1121,10 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
             const uint32_t lenp = act ? cl_[ps] : 0u;
             const bool conv = tyu != T_NONE && (fd_[ps] || E.nulcut);
             // (a time column has an instance of its own: the other types' code stays as it is)
-            const bool sc = tyu == T_TIME
+            const bool sc = SPECIAL && tyu == T_TIME
                                 ? cell_simple<false, true>(w4, lenp, cv_[ps], tyu, conv, E.p10, E.tz_offset, flen, elo, ehi, value, valid)
+                            : SPECIAL && tyu == T_F32
+                                ? cell_simple<false, false, true>(w4, lenp, cv_[ps], tyu, conv, E.p10, E.tz_offset, flen, elo, ehi, value, valid)
                             : __builtin_amdgcn_ballot_w64(lenp > 8) == 0
                                 ? cell_simple<true>(w4, lenp, cv_[ps], tyu, conv, E.p10, E.tz_offset, flen, elo, ehi, value, valid)
                                 : cell_simple<false>(w4, lenp, cv_[ps], tyu, conv, E.p10, E.tz_offset, flen, elo, ehi, value, valid);
@@ -1921,7 +1937,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             }
             const ColOut O = colout[c];
             const uint64_t gb = O.base + tiletot[c];
-            const uint32_t total = column_cells<WRITE>(E, O, c, typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
+            const uint32_t total = column_cells<WRITE, true>(E, O, c, typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
             if (lane == 0) tiletot[c] += total;  // this wave owns column c
         }
         if (WRITE && deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
@@ -1968,6 +1984,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
 // search.  A block loads its tile (and the head of its first record from the look-behind),
 // rebuilds the digit bitmap, reads each cell's source from the map and runs the same column
 // routine as the tile kernel.  Tiles without a map are left to tile_kernel<true>.
+template <bool SPECIAL>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void emit_kernel(const TileParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     const LdsLayout &L = P.L;
@@ -2151,7 +2168,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             const ColOut O = colout[c];
             const uint64_t gb = O.base + tiletot[c];
             const uint32_t total =
-                column_cells<true>(E, O, c, cols[c].typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
+                column_cells<true, SPECIAL>(E, O, c, cols[c].typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
             if (lane == 0) tiletot[c] += total;  // this wave owns column c
         }
         __syncthreads();
@@ -2307,13 +2324,18 @@ hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_
 hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream) {
     if (P.ntiles == 0) return hipSuccess;
     if (!P.cellmap || !P.map_stride) return hipSuccess;  // no map at all: the full write kernel does every tile
-    hipError_t e = hipFuncSetAttribute((const void *)emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (schemas with time or binary32 columns take the instance that converts them on the spot)
+    const void *fn = P.special_cols ? (const void *)emit_kernel<true> : (const void *)emit_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     uint32_t lds = P.L.total;
 #ifdef MDC_ABLATE
     if (const char *e = getenv("MDC_DEBUG_LDS")) lds = (uint32_t)atoi(e);  // occupancy experiments
 #endif
-    hipLaunchKernelGGL(emit_kernel, dim3(P.ntiles), dim3(BLOCK), lds, stream, P);
+    if (P.special_cols)
+        hipLaunchKernelGGL(emit_kernel<true>, dim3(P.ntiles), dim3(BLOCK), lds, stream, P);
+    else
+        hipLaunchKernelGGL(emit_kernel<false>, dim3(P.ntiles), dim3(BLOCK), lds, stream, P);
     return hipGetLastError();
 }
 

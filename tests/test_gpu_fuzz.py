@@ -143,3 +143,63 @@ def test_random_delimited(port, seed):
         assert_batches_equal(got, exp, f"seed {seed}")
     finally:
         p.close()
+
+
+def binary32_traps(n, seed=5):
+    """Decimals of at most 16 bytes whose correctly rounded binary64 value lies exactly half way
+    between two binary32 values although the decimal does not: rounding twice gives the wrong
+    binary32 for about a third of them."""
+    import struct
+    from fractions import Fraction
+    f32 = lambda x: struct.unpack("<f", struct.pack("<f", x))[0]
+    rng = random.Random(seed)
+    out = []
+    while len(out) < n:
+        k = rng.choice([13, 14])
+        v = f32(10 ** (rng.uniform(14, 14.99) - k))
+        b = struct.unpack("<I", struct.pack("<f", v))[0]
+        v2 = struct.unpack("<f", struct.pack("<I", b + 1))[0]
+        mid = Fraction(v) + (Fraction(v2) - Fraction(v)) / 2
+        m = round(mid * 10 ** k)
+        if m >= 10 ** 15 or Fraction(m, 10 ** k) == mid or Fraction(m / 10 ** k) != mid:
+            continue
+        s = str(m).rjust(k + 1, "0")
+        out.append((s[:-k] + "." + s[-k:]).encode())
+    return out
+
+
+def test_plain_binary32_cells(port):
+    """Whole waves of short plain numbers into binary32 columns (the write pass's straight-line
+    conversion), among them exact ties, the double-rounding traps and signed zeros."""
+    rng = random.Random(77)
+    traps = binary32_traps(400)
+    assert all(len(t) <= 16 for t in traps)
+    fixed = [b"16777217", b"16777219", b"33554434", b"-16777217", b"0.1", b"12.7", b"-0", b"-0.0", b"+.5", b"5.", b"0", b".",
+             b"-", b"", b"340282350000000", b"0.00000000000001", b"8388608.5", b"8388609.5", b"4194304.25", b"4194304.75"]
+    cols = [Col("a", "number", 22), Col("b", "number", 22), Col("c", "char", 16), Col("d", "date", 14)]
+    typed = [schema.T_F32] * 4
+    recs = []
+    for i in range(30000):
+        vals = []
+        for _ in range(4):
+            k = rng.random()
+            if (i // 200) % 5:  # four blocks of five without traps: their waves stay on the straight-line path
+                k = 0.06 + 0.94 * k
+            if k < 0.03:
+                vals.append(rng.choice(traps))
+            elif k < 0.06:
+                vals.append(rng.choice(fixed))
+            elif k < 0.6:
+                vals.append(b"%.*f" % (rng.randint(0, 6), rng.uniform(-2000, 2000)))
+            else:
+                vals.append(b"%d.%0*d" % (rng.randint(0, 10 ** rng.randint(1, 8)), rng.randint(1, 6), rng.randint(0, 999999) % 10 ** 6))
+        vals = [v[:16] for v in vals]
+        recs.append(b"<a>%s</a><b>%s</b><c>%s</c><d>%s</d><endl/>\n" % tuple(vals))
+    data = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    exp = port.parse_xml(data, cols, typed=typed)
+    p = capi.Parser.xml(cols, typed=typed)
+    try:
+        assert_batches_equal(p.parse_host(data).to_host(), exp, "binary32")
+    finally:
+        p.close()
+    assert int(np.count_nonzero(exp.valid[:, 0] & 1)) > 29000
