@@ -1948,6 +1948,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         if (WRITE && (uint32_t)tid < RBn) {
             const uint64_t row = row0 + rb0 + tid;
             if (P.rec_off) P.rec_off[row + 1] = (uint64_t)(base_pos + (int64_t)recend[tid + 1] + 1);
+#pragma unroll 1  // (one word for up to 32 columns: an unrolled loop only costs scalar registers)
             for (uint32_t w = 0; w < W; ++w) {
                 P.valid[row * W + w] = vmask[tid * W + w];
                 P.found[row * W + w] = fmask[tid * W + w];
@@ -2177,6 +2178,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             if (P.rec_off)
                 P.rec_off[row + 1] =
                     (uint64_t)(base_pos + (int64_t)mapl[ncols * RB + tid] + 1);
+#pragma unroll 1  // (one word for up to 32 columns: an unrolled loop only costs scalar registers)
             for (uint32_t w = 0; w < W; ++w) {
                 P.valid[row * W + w] = vmask[tid * W + w];
                 P.found[row * W + w] = fmask[tid * W + w];
