@@ -1460,6 +1460,18 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             __syncthreads();
         }
     }
+    // NUL bytes of the first record's part in the look-behind count as well (a chunk that begins in
+    // front of the record may add the record before: the flag only has to be set when a NUL is there)
+    if (tile_start > 0) {
+        bool nul = false;
+        for (int j = s0_li / CHUNK + tid; j < ts_li / CHUNK; j += BLOCK) {
+            const uint4 c4 = ((const uint4 *)sdata)[j];
+            nul |= ((((c4.x - 0x01010101u) & ~c4.x) | ((c4.y - 0x01010101u) & ~c4.y) | ((c4.z - 0x01010101u) & ~c4.z) |
+                     ((c4.w - 0x01010101u) & ~c4.w)) & 0x80808080u) != 0;
+        }
+        if (nul) ms[MS_HASNUL] = 1;
+        __syncthreads();
+    }
     const bool has_nul = ms[MS_HASNUL] != 0;
     // the tile's place in the cell map: map_stride record slots per tile, no allocation needed
     const uint32_t map_slot = (!WRITE && P.cellmap && nrec <= P.map_stride) ? blockIdx.x * P.map_stride : NONE;

@@ -24,7 +24,7 @@ def random_schema(rng):
         stem = rng.choice(["", "a", "ab", "obt", "val", "x_"])
         names.add((stem + "".join(rng.choice("abcdxyz0189_") for _ in range(k)))[:31] or "q")
     cols, typed = [], []
-    for nm in sorted(names, key=lambda _: rng.random()):
+    for nm in sorted(sorted(names), key=lambda _: rng.random()):  # (a set's order differs from process to process)
         dt = rng.choice(["char", "date", "number", "number"])
         cl = {"date": 14, "number": 22}.get(dt, rng.choice([0, 1, 5, 10, 30]))
         if rng.random() < 0.15:

@@ -466,3 +466,27 @@ def test_full_size_batch_equals_its_parts(port):
         assert np.array_equal(whole.off[c][: exp.rows + 1], exp.off[c])
         assert np.array_equal(whole.data[c][: int(exp.off[c][exp.rows])], exp.data[c])
     p.close()
+
+
+@pytest.mark.parametrize("typed_text", [False, True])
+def test_nul_in_the_part_of_a_record_that_lies_in_the_tile_before(port, typed_text):
+    """A record that starts in one 16 KiB tile and ends in the next, with its NUL byte in the first
+    part: the tile that owns the record must cut the text cell at the NUL like c_str() does, whether
+    or not it holds a NUL byte of its own, and the rows behind it must keep their places."""
+    cols = [Col("a", "char", 10), Col("n", "number", 22), Col("t", "char", 0)]
+    typed = [schema.T_I32 if typed_text else schema.T_NONE, schema.T_F64, schema.T_NONE]
+    plain = b"<a>abc</a><n>12.5</n><t>text</t><endl/>\n"
+    for tail in (40, 300, 3000):  # bytes of the straddling record in the second tile
+        head = plain * ((16384 - 200) // len(plain))
+        filler = 16384 + tail - len(head) - len(b"<a>x\x00y</a><n>7</n><t></t><endl/>\n")
+        straddler = b"<a>x\x00y</a><n>7</n><t>" + b"q" * filler + b"</t><endl/>\n"
+        data = np.frombuffer(head + straddler + plain * 600, dtype=np.uint8)
+        assert 8 < 16384 - len(head) < 300 and len(head) + len(straddler) == 16384 + tail
+        exp = port.parse_xml(data, cols, typed=typed)
+        p = capi.Parser.xml(cols, typed=typed)
+        try:
+            assert_batches_equal(p.parse_host(data).to_host(), exp, f"tail {tail}")
+        finally:
+            p.close()
+        r = len(head) // len(plain)
+        assert exp.cell(r, 0) == b"x" and exp.cell(r + 1, 0) == b"abc"

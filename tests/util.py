@@ -12,6 +12,9 @@ def assert_batches_equal(a, b, what=""):
             r = int(np.nonzero(a.off[c] != b.off[c])[0][0])
             raise AssertionError(f"{what}: col {c} offsets differ first at row {r - 1}: "
                                  f"{a.cell(max(r - 1, 0), c)!r} vs {b.cell(max(r - 1, 0), c)!r}")
+        if len(a.data[c]) != len(b.data[c]):
+            raise AssertionError(f"{what}: col {c} holds {len(a.data[c])} bytes, expected {len(b.data[c])}; the offsets end at "
+                                 f"{int(a.off[c][a.rows])}; last cells {[a.cell(r, c) for r in range(max(0, a.rows - 3), a.rows)]!r}")
         if not np.array_equal(a.data[c], b.data[c]):
             i = int(np.nonzero(a.data[c] != b.data[c])[0][0])
             r = int(np.searchsorted(a.off[c], i, side="right")) - 1
