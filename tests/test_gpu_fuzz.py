@@ -30,8 +30,23 @@ def random_schema(rng):
         if rng.random() < 0.15:
             cl = rng.choice([0, 3, 40])
         cols.append(Col(nm, dt, cl))
-        typed.append(rng.choice([-1, -1, 0, 1, 2, 3, 4, 5, 6, 7]))
+        typed.append(rng.choice([-1, -1, 0, 1, 2, 3, 4, 5, 6, 7, 8]))
     return cols, typed
+
+
+@pytest.fixture
+def utc():
+    """Time columns: the checker's mktime runs in the process's zone, the parser's default is UTC."""
+    import time
+    old = os.environ.get("TZ")
+    os.environ["TZ"] = "UTC0"
+    time.tzset()
+    yield
+    if old is None:
+        os.environ.pop("TZ", None)
+    else:
+        os.environ["TZ"] = old
+    time.tzset()
 
 
 def resolve(cols, typed):
@@ -40,7 +55,7 @@ def resolve(cols, typed):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MDC_FUZZ_SEEDS", "24"))))  # (more seeds for a longer hunt)
-def test_random_schema(port, seed):
+def test_random_schema(port, seed, utc):
     rng = random.Random(1000 + seed)
     cols, typed = random_schema(rng)
     ty = resolve(cols, typed)
