@@ -218,3 +218,43 @@ def test_plain_binary32_cells(port):
     finally:
         p.close()
     assert int(np.count_nonzero(exp.valid[:, 0] & 1)) > 29000
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MDC_FUZZ_SEEDS", "24"))))
+def test_random_long_records(port, seed, utc):
+    """Records of a few hundred bytes to about 15 KiB (every one spans tiles, the larger look-behind
+    levels come into play), long cells with tag-like text, NUL bytes and digits inside, clips at
+    4000 bytes or none."""
+    rng = random.Random(9000 + seed)
+    ncols = rng.choice([2, 3, 5, 8])
+    cols, typed = [], []
+    for i in range(ncols):
+        dt = rng.choice(["char", "char", "number", "date"])
+        cl = {"date": 14, "number": 22}.get(dt, rng.choice([0, 10, 4000]))
+        cols.append(Col("f%d%s" % (i, "x" * rng.randrange(0, 9)), dt, cl))
+        typed.append(rng.choice([0, 0, 1, 3, 5, 6, 8]))
+    carry = rng.random() < 0.7
+    pool = b"abcXYZ 0123456789.-+<>/\x00\n\r" + b"".join(b"<" + c.colname.encode() + b">" for c in cols[:2])
+    big = rng.choice([300, 2000, 6000])
+    recs = []
+    for _ in range(rng.choice([30, 150])):
+        out = bytearray()
+        for c in cols:
+            if rng.random() < 0.1:
+                continue  # no such field in this record
+            n = rng.randrange(0, 20) if rng.random() < 0.7 else rng.randrange(0, big)
+            v = bytes(rng.choice(pool) for _ in range(n)) if rng.random() < 0.5 else (b"%d" % rng.randrange(10 ** 15))[: max(n, 1)] * (n // 15 + 1)
+            v = v.replace(b"<endl/>\n", b"")
+            nm = c.colname.encode()
+            out += b"<" + nm + b">" + v + b"</" + nm + b">"
+        recs.append(bytes(out) + b"<endl/>\n")
+    recs = [r for r in recs if len(r) < 16000]  # (longer records are refused as a whole: another test's subject)
+    data = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    print("seed", seed, "ncols", ncols, "carry", carry, "records", len(recs), "bytes", data.size, "longest", max(map(len, recs)), flush=True)
+    exp = port.parse_xml(data, cols, typed=typed, carry=carry)
+    p = capi.Parser.xml(cols, typed=typed, carry=carry)
+    try:
+        assert_batches_equal(p.parse_host(data).to_host(), exp, f"seed {seed}")
+        assert_batches_equal(p.parse_host(data).to_host(), exp, f"seed {seed} again")
+    finally:
+        p.close()
