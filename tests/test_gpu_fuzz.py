@@ -131,6 +131,8 @@ def random_lines(rng, nlines, sep: bytes, nfields, regular):
             k = rng.choice([0, 1, nfields - 1, nfields, nfields, nfields + 1, nfields + 3])
             fields = [rng.choice(odd) if rng.random() < 0.5 else bytes(rng.choice(b"0123456789.-+ abT") for _ in range(rng.randrange(0, 20)))
                       for _ in range(k)]
+        if rng.random() < 0.02 and fields:  # now and then a long field: lines that span tiles
+            fields[rng.randrange(len(fields))] = bytes(rng.choice(b"0123456789.- abc\x00") for _ in range(rng.randrange(100, 6000)))
         out += sep.join(fields) + b"\n"
     if rng.random() < 0.5:
         out += b"unterminated" + sep + b"tail"
