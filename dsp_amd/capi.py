@@ -82,6 +82,8 @@ class CTiming(ctypes.Structure):
         ("rows", ctypes.c_int64),
         ("tiles", ctypes.c_int),
         ("full_write", ctypes.c_int),
+        ("lookup_tiles", ctypes.c_int),
+        ("reserved", ctypes.c_int),
     ]
 
 

@@ -182,6 +182,7 @@ struct mdc_parser {
     uint64_t *d_base = nullptr;
     uint32_t *d_status = nullptr;
     uint32_t *d_tmpl = nullptr;     // tag template (see TMPL_MAX): built from the first input, kept while the
+    uint32_t tmpl_sample = 0;       // the record the next template is taken from (cycles when tiles do not follow)
     bool tmpl_valid = false;        // inputs follow it (any template of this schema gives right results: a tile
                                     // whose records differ takes the table lookup), rebuilt when many tiles do not
     uint32_t *d_hdr = nullptr;      // per tile: cell map slot, first record start
@@ -696,6 +697,7 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     P.tile_hdr = p->d_hdr;
     P.tmpl = p->d_tmpl;
     P.use_tmpl = p->mode == MODE_XML ? 1u : 0u;
+    P.tmpl_sample = p->tmpl_sample;
     for (int t : p->typed)
         if (t == MDC_T_TIME || t == MDC_T_F32) P.special_cols = 1;
 #ifdef MDC_ABLATE
@@ -727,7 +729,13 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
             // keep a template that exists and that most tiles followed
             const uint64_t left = p->h_report[0] >> 32;
             if (build_tmpl) p->tmpl_valid = (uint32_t)p->h_totals[ncnt + 1] != 0;
-            if (left * 8 > ntiles) p->tmpl_valid = false;
+            if (left * 8 > ntiles || (build_tmpl && !p->tmpl_valid)) {
+                // few tiles followed (or the sampled record gave no template): the next parse samples
+                // another record, in case this one was the odd one out
+                p->tmpl_valid = false;
+                p->tmpl_sample = (p->tmpl_sample + 1) % 4;
+            }
+            p->timing.lookup_tiles = (int)left;
         }
         if (((uint32_t)p->h_report[0] & ST_RECORD_TOO_LONG) && p->lb_level < 2) {
             ++p->lb_level;

@@ -161,6 +161,7 @@ struct TileParams {
     uint32_t *tmpl;              // tag template (always a valid pointer; word 0 == 0: none)
     uint32_t use_tmpl;           // tagged input: the sizing pass may use the template
     uint32_t special_cols;       // the schema has time or binary32 columns (picks the write kernel's instance)
+    uint32_t tmpl_sample;        // which record the template kernel samples: 0 = the second of the input, 1 = the third ...
     uint32_t debug;  // diagnostic builds only: phases to skip (ablation timing)
 };
 

@@ -428,7 +428,8 @@ __device__ __forceinline__ bool tmpl_event(const uint8_t *sdata, const uint4 *tl
 }
 
 // Builds the tag template from the second record of the input (the first one that starts right
-// behind a terminator).  One wave; lane l looks at bytes [64 l, 64 l + 64) of the first
+// behind a terminator), or a later one when the host asks for it (the records of an input need not
+// look like its second one).  One wave; lane l looks at bytes [64 l, 64 l + 64) of the first
 // TMPL_WINDOW bytes.  No template (word 0 = 0) when the window holds no two terminators, the
 // record has no or too many '<', a tag text is longer than TMPL_MAXLEN or holds a newline, an
 // event matches two patterns or two events match the same one.
@@ -494,10 +495,12 @@ __global__ __launch_bounds__(64) void template_kernel(const TileParams P) {
         const uint32_t cnt = (uint32_t)__builtin_popcountll(tm);
         uint32_t rank = wave_incl_scan(cnt) - cnt;
         uint64_t t = tm;
-        while (t && rank < 2) {
+        // the sampled record lies between terminators P.tmpl_sample and P.tmpl_sample + 1
+        while (t && rank < P.tmpl_sample + 2) {
             const int b = __builtin_ctzll(t);
             t &= t - 1;
-            tpos[rank++] = lane * 64 + b;
+            if (rank >= P.tmpl_sample) tpos[rank - P.tmpl_sample] = lane * 64 + b;
+            ++rank;
         }
     }
     __syncthreads();

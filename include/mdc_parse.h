@@ -109,6 +109,9 @@ typedef struct mdc_timing {
     int64_t rows;
     int tiles;
     int full_write;  /* 1 = some tiles had no cell map and went through the full write kernel */
+    int lookup_tiles; /* tagged input: tiles whose records did not all repeat the sampled record's tags */
+                      /* and took the tag table instead (0 for delimited input)                         */
+    int reserved;
 } mdc_timing;
 
 /* ---- library ------------------------------------------------------------------------ */

@@ -490,3 +490,27 @@ def test_nul_in_the_part_of_a_record_that_lies_in_the_tile_before(port, typed_te
             p.close()
         r = len(head) // len(plain)
         assert exp.cell(r, 0) == b"x" and exp.cell(r + 1, 0) == b"abc"
+
+
+def test_template_is_taken_from_another_record_when_the_second_is_the_odd_one(port):
+    """Regular records whose second one lacks a field: the first parse samples it and no tile follows;
+    the parse after that samples the third record and nearly every tile follows (mdc_timing's
+    lookup_tiles), with the same results."""
+    import re
+    a, _ = gen.mind_xml(rows=30000)
+    recs = a.tobytes().split(b"<endl/>\n")
+    recs[1] = re.sub(rb"<wd>[^<]*</wd>", b"", recs[1])
+    data = np.frombuffer(b"<endl/>\n".join(recs), dtype=np.uint8)
+    exp = port.parse_xml(data, schema.ZHOBTMIND)
+    p = capi.Parser.xml(schema.ZHOBTMIND)
+    try:
+        left = []
+        for i in range(3):
+            b = p.parse_host(data)
+            t = p.timing()
+            left.append((t.lookup_tiles, t.tiles))
+            assert_batches_equal(b.to_host(), exp, f"parse {i}")
+        assert left[0][0] > left[0][1] // 2, left      # the odd record as the sample: the tiles leave the template
+        assert left[1][0] <= 2 and left[2][0] <= 2, left  # another sample: only the odd record's tile does
+    finally:
+        p.close()
