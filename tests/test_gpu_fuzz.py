@@ -260,3 +260,20 @@ def test_random_long_records(port, seed, utc):
         assert_batches_equal(p.parse_host(data).to_host(), exp, f"seed {seed} again")
     finally:
         p.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MDC_FUZZ_SEEDS", "24"))))
+def test_random_format(port, seed):
+    """The writer side on random columns: 1 to 40 fields, names of 1 to 40 bytes, values from empty to
+    a few thousand bytes with NUL bytes now and then, cuts or none, files of any number of rows."""
+    import test_gpu_format as tgf
+    rng = random.Random(11000 + seed)
+    nf = rng.choice([1, 2, 3, 7, 11, 24, 40])
+    nrows = rng.choice([0, 1, 2, 63, 64, 65, 500, 3000])
+    maxlen = rng.choice([0, 3, 12, 40, 300])
+    rows = cases.random_rows(12000 + seed, nrows, nf, maxlen=maxlen, nul=rng.choice([0, 0, 0.01, 0.2]),
+                             big=rng.choice([0, 0, 0.002]) if maxlen else 0)
+    names = ["".join(rng.choice("abcxyz_019") for _ in range(rng.choice([1, 2, 5, 9, 17, 40]))) for _ in range(nf)]
+    fl = None if rng.random() < 0.5 else [rng.choice([0, 0, 1, 4, 10, 100]) for _ in range(nf)]
+    for mc in {0, rng.choice([1, 7, 64, 1000])}:
+        tgf.check_against(port, names, fl, rows, mc, f"seed {seed} maxcount {mc}")
