@@ -197,6 +197,9 @@ struct mdc_parser {
     void **h_ptrs = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     mdc_timing timing{};
+    // test hook (mdc_internal_skew_counts): the next parse changes one counter of the sizing pass
+    // before the scan, so that the write pass meets a tile that was sized wrongly
+    int skew_tile = -1, skew_col = 0, skew_delta = 0;
 };
 
 struct mdc_batch {
@@ -718,6 +721,14 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
         const bool build_tmpl = P.use_tmpl && !p->tmpl_valid && ntiles;
         if (build_tmpl) HIP_TRY(launch_template_kernel(P, s));
         HIP_TRY(launch_tile_kernel(false, P, s));
+        if (p->skew_tile >= 0 && (size_t)p->skew_tile < ntiles && p->skew_col >= 0 && p->skew_col < (int)ncols) {
+            uint32_t *w = p->d_counts + (size_t)p->skew_tile * ncnt + p->skew_col, v = 0;
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipMemcpy(&v, w, 4, hipMemcpyDeviceToHost));
+            v += (uint32_t)p->skew_delta;
+            HIP_TRY(hipMemcpy(w, &v, 4, hipMemcpyHostToDevice));
+            p->skew_tile = -1;
+        }
         HIP_TRY(hipEventRecord(p->ev[1], s));
         HIP_TRY(launch_scan_tiles(p->d_counts, p->d_base, (uint32_t)ntiles, ncnt, (uint64_t *)p->d_status + REPORT_TOTALS, s));
         HIP_TRY(hipEventRecord(p->ev[2], s));
@@ -804,6 +815,15 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     ALLOC_OR_FAIL(rows * p->words * 4 + 4, b->d_found, uint32_t *);
     bytes_out += 2 * rows * p->words * 4;
     ALLOC_OR_FAIL(3 * (size_t)ncols * sizeof(void *), b->d_ptrs, void *);
+    // from here on a failed runtime call gives the half-built batch back before it returns
+#define HIP_TRY_B(expr)                                                                \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            batch_release(b);                                                          \
+            return fail(MDC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));          \
+        }                                                                              \
+    } while (0)
     {
         // (from pinned memory that lives until the parser's next call: no wait for the copy here)
         void **hp = p->h_ptrs;
@@ -812,12 +832,12 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
             hp[ncols + c] = b->d_bytes[c];
             hp[2 * ncols + c] = b->d_val[c];
         }
-        HIP_TRY(hipMemcpyAsync(b->d_ptrs, hp, 3 * (size_t)ncols * sizeof(void *), hipMemcpyHostToDevice, s));
+        HIP_TRY_B(hipMemcpyAsync(b->d_ptrs, hp, 3 * (size_t)ncols * sizeof(void *), hipMemcpyHostToDevice, s));
     }
     if (ntiles == 0) {
         // nothing to launch: every offset array is the single entry 0
-        for (uint32_t c = 0; c < ncols; ++c) HIP_TRY(hipMemsetAsync(b->d_off[c], 0, 4, s));
-        if (b->d_rec_off) HIP_TRY(hipMemsetAsync(b->d_rec_off, 0, 8, s));
+        for (uint32_t c = 0; c < ncols; ++c) HIP_TRY_B(hipMemsetAsync(b->d_off[c], 0, 4, s));
+        if (b->d_rec_off) HIP_TRY_B(hipMemsetAsync(b->d_rec_off, 0, 8, s));
     }
     P.rec_off = b->d_rec_off;
     P.off = (uint32_t *const *)b->d_ptrs;
@@ -825,7 +845,7 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     P.val = (uint64_t *const *)((void **)b->d_ptrs + 2 * ncols);
     P.valid = b->d_valid;
     P.found = b->d_found;
-    HIP_TRY(hipEventRecord(p->ev[2], s));
+    HIP_TRY_B(hipEventRecord(p->ev[2], s));
     // tiles with a complete cell map take the short write kernel, the others the full one
     P.L = p->LEs[p->lb_level];
     hipError_t le = launch_emit_kernel(P, s);
@@ -838,8 +858,8 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
         batch_release(b);
         return fail(MDC_ERR_HIP, "launch: %s", hipGetErrorString(le));
     }
-    HIP_TRY(hipEventRecord(p->ev[3], s));
-    HIP_TRY(hipMemcpyAsync(p->h_report, p->d_status, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY_B(hipEventRecord(p->ev[3], s));
+    HIP_TRY_B(hipMemcpyAsync(p->h_report, p->d_status, 4, hipMemcpyDeviceToHost, s));
     hipError_t se = hipStreamSynchronize(s);
     if (se != hipSuccess) {
         batch_release(b);
@@ -898,6 +918,16 @@ extern "C" int mdc_parse_host(mdc_parser *p, const void *h_data, size_t n, mdc_b
 // used by mdc_stream.cpp, which is built on the public entry points
 extern "C" int mdc_internal_fail(int code, const char *msg) { return fail(code, "%s", msg); }
 extern "C" int mdc_internal_parser_device(const mdc_parser *p) { return p->dev->id; }
+// Test hook: the next parse on `p` adds `delta` to what its sizing pass counted for column `col` of
+// tile `tile`, as a sizing pass that disagreed with the write pass would have left it.  The write
+// pass must answer with MDC_ERR_INTERNAL and store nothing outside what was sized.
+extern "C" int mdc_internal_skew_counts(mdc_parser *p, int tile, int col, int delta) {
+    if (!p) return fail(MDC_ERR_ARG, "NULL argument");
+    p->skew_tile = tile;
+    p->skew_col = col;
+    p->skew_delta = delta;
+    return MDC_OK;
+}
 
 extern "C" int mdc_parse_file(mdc_parser *p, const char *path, mdc_batch **out) {
     if (!p || !out || !path) return fail(MDC_ERR_ARG, "NULL argument");

@@ -1089,6 +1089,7 @@ struct ColOut {
 // and, when WRITE, stores values, end offsets and the filtered bytes (staged in LDS, then
 // 16-byte stores).  gb = global byte position of the batch's first cell in the column arena,
 // rowbase = global row of the batch's first record.  Returns the column's bytes in this batch.
+// room = bytes the sizing pass counted for this column in this tile that are not yet written.
 // SPECIAL: the straight-line path also converts time and binary32 columns (instances of their
 // own; a kernel for schemas without such columns does not carry their code).
 template <bool WRITE, bool SPECIAL>
@@ -1096,7 +1097,7 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
                                                  int lane, uint32_t RBn, uint64_t rowbase, uint64_t gb,
                                                  const uint32_t (&cs_)[RB_PASSES], const uint32_t (&cl_)[RB_PASSES],
                                                  const uint32_t (&cv_)[RB_PASSES], const bool (&fd_)[RB_PASSES],
-                                                 bool &deferred) {
+                                                 bool &deferred, uint32_t room, bool &overrun) {
     const uint8_t *const sdata = E.sdata;
     gmem_u64 *const valp = (WRITE && typed != T_NONE) ? (gmem_u64 *)O.val : nullptr;
     uint32_t cf_[RB_PASSES], cx_[RB_PASSES];
@@ -1194,7 +1195,11 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
         cx_[ps] = total + incl - flen;
         total += wave_last(incl);
     }
-    if (WRITE && !E.nostore) {
+    // The arenas are sized by the sizing pass, which measures every cell with code of its own: a
+    // batch that would write more than that pass left for this column in this tile stores nothing
+    // (the host then reports an internal error instead of the kernel writing out of bounds).
+    if (WRITE && total > room) overrun = true;
+    if (WRITE && !E.nostore && total <= room) {
         const uint32_t a = (uint32_t)(gb & 15);
         const bool staged = a + total <= E.wstage_cap;
         gmem_u32 *const offp = (gmem_u32 *)O.off;
@@ -1361,7 +1366,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     // tagged input, sizing pass: records that repeat the sample record's tags take the template
     const bool tmode = !WRITE && !csv && P.use_tmpl && nT_in != 0 && nT_in <= tmpl_cap;
     const uint32_t nT = nT_in;
-    uint32_t *coltot = (uint32_t *)(smem + L.coltot);  // totals of the current batch
+    uint32_t *coltot = (uint32_t *)(smem + L.coltot);  // write pass: the sizing pass's bytes per column of this tile
     uint32_t *tiletot = coltot + (ncols + 1);          // totals of the batches done so far
     for (uint32_t c = tid; c < ncols + 1; c += BLOCK) tiletot[c] = 0;
     STAMP(0);  // loads
@@ -1482,7 +1487,13 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     const uint64_t *tb = WRITE ? P.tile_base + (uint64_t)blockIdx.x * (ncols + 1) : nullptr;
     const uint64_t row0 = WRITE ? tb[ncols] : 0;
     ColOut *colout = (ColOut *)(smem + L.colout);
-    if (WRITE)
+    if (WRITE) {
+        // what the sizing pass counted for this tile: the rows must agree before anything is stored
+        const uint32_t *tc = P.tile_counts + (uint64_t)blockIdx.x * (ncols + 1);
+        if (tc[ncols] != nrec) {
+            if (tid == 0) atomicOr(P.status, ST_INTERNAL);
+            return;
+        }
         for (uint32_t c = tid; c < ncols; c += BLOCK) {
             ColOut o;
             o.off = P.off[c];
@@ -1490,7 +1501,9 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             o.val = P.val[c];
             o.base = tb[c];
             colout[c] = o;
+            coltot[c] = tc[c];
         }
+    }
     if (WRITE && blockIdx.x == 0) {
         if (tid == 0 && P.rec_off) P.rec_off[0] = 0;
         for (uint32_t c = tid; c < ncols; c += BLOCK) P.off[c][0] = 0;
@@ -1740,7 +1753,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         // ---- E-H. one wave per column, one lane per record; everything about a column (cell
         // descriptors, lengths, typed values, offsets, staging, copy-out) stays inside the wave,
         // so no block barrier is needed until the row outputs
-        bool deferred = false;
+        bool deferred = false, overrun = false;
         CellEnv E;
         E.sdata = sdata;
         E.has_nul = has_nul;
@@ -1952,10 +1965,13 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             }
             const ColOut O = colout[c];
             const uint64_t gb = O.base + tiletot[c];
-            const uint32_t total = column_cells<WRITE, true>(E, O, c, typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
-            if (lane == 0) tiletot[c] += total;  // this wave owns column c
+            const uint32_t done = (uint32_t)(gb - O.base);
+            const uint32_t total = column_cells<WRITE, true>(E, O, c, typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred,
+                                                             coltot[c] - done, overrun);
+            if (lane == 0) tiletot[c] = done + total;  // this wave owns column c
         }
         if (WRITE && deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
+        if (WRITE && overrun) atomicOr(P.status, ST_INTERNAL);
         __syncthreads();
         STAMP(5);  // cells: descriptors, lengths, values, staging, copy-out
         if (mapping && (uint32_t)tid < RBn)
@@ -1978,6 +1994,11 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         __syncthreads();
     }
 
+    if (WRITE) {
+        // (the batch loop ends with a barrier) every column must have come out as long as it was sized
+        for (uint32_t c = tid; c < ncols; c += BLOCK)
+            if (tiletot[c] != coltot[c]) atomicOr(P.status, ST_INTERNAL);
+    }
     if (!WRITE) {
         if (tmode && irregular && tid == 0) atomicAdd(P.status + 1, 1u);  // the host renews a template few tiles follow
         uint32_t *tc = P.tile_counts + (uint64_t)blockIdx.x * (ncols + 1);
@@ -2083,6 +2104,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     // of the schema only the header, the columns and the powers of ten (the tag table stays out)
     const uint32_t sch_head = (uint32_t)sizeof(SchemaHdr) + ((ncols * (uint32_t)sizeof(DevCol) + 15) & ~15u);
     uint32_t *tiletot = (uint32_t *)(smem + L.coltot);
+    uint32_t *sized = tiletot + (ncols + 1);  // the sizing pass's bytes per column of this tile
     ColOut *colout = (ColOut *)(smem + L.colout);
     const uint64_t *tb = P.tile_base + (uint64_t)tile * (ncols + 1);
     {
@@ -2103,10 +2125,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         o.bytes = P.bytes[cc];
         o.val = P.val[cc];
         o.base = tb[cc];
+        const uint32_t szv = P.tile_counts[(uint64_t)tile * (ncols + 1) + cc];
         s[si] = sv;
         for (uint32_t i = tid + BLOCK; i < sch16; i += BLOCK) s[i] = g[i];
         sp[pi] = pv;
         tiletot[cc] = 0;
+        sized[cc] = szv;
         colout[cc] = o;
     }
     const uint32_t hslot = __builtin_amdgcn_readfirstlane(hslot_v);
@@ -2158,7 +2182,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
 #ifdef MDC_ABLATE
     E.dbg = P.debug;
 #endif
-    bool deferred = false;
+    bool deferred = false, overrun = false;
     for (uint32_t rb0 = 0; rb0 < nrec; rb0 += RB) {
         const uint32_t RBn = (nrec - rb0 < RB) ? nrec - rb0 : RB;
         if (rb0) load_map(rb0, RBn);  // (the previous batch ended with a barrier)
@@ -2182,10 +2206,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
                 if (fd_[ps]) atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
             }
             const ColOut O = colout[c];
-            const uint64_t gb = O.base + tiletot[c];
-            const uint32_t total =
-                column_cells<true, SPECIAL>(E, O, c, cols[c].typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_, fd_, deferred);
-            if (lane == 0) tiletot[c] += total;  // this wave owns column c
+            const uint32_t done = tiletot[c];
+            const uint64_t gb = O.base + done;
+            const uint32_t total = column_cells<true, SPECIAL>(E, O, c, cols[c].typed, lane, RBn, row0 + rb0, gb, cs_, cl_, cv_,
+                                                               fd_, deferred, sized[c] - done, overrun);
+            if (lane == 0) tiletot[c] = done + total;  // this wave owns column c
         }
         __syncthreads();
         if ((uint32_t)tid < RBn) {
@@ -2202,6 +2227,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         __syncthreads();
     }
     if (deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
+    // (the batch loop ends with a barrier) every column must have come out as long as it was sized
+    bool differ = overrun;
+    for (uint32_t c = tid; c < ncols; c += BLOCK) differ |= tiletot[c] != sized[c];
+    if (differ) atomicOr(P.status, ST_INTERNAL);
 }
 
 // Exclusive prefix over tiles of every counter, in two small kernels.  (1) One block per

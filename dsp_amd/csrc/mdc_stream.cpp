@@ -7,8 +7,10 @@
 //
 // Replaces the per-file loop of the reference's ingest (tools/xmltodb.cpp:147-218, one file at a
 // time: open, read, parse) for inputs that tools/gzipfiles.cpp:59 has compressed.  Built on the
-// public entry points of mdc_parse.h plus the HIP runtime; all GPU calls are made on the thread
-// that calls mdc_stream_next.
+// public entry points of mdc_parse.h plus the HIP runtime.  Kernel launches, copies and stream
+// waits are made on the thread that calls mdc_stream_next; the worker threads bind the parser's
+// device (hipSetDevice) only to allocate and free their pinned buffers (hipHostMalloc,
+// hipHostFree) and touch no stream.
 #include <hip/hip_runtime.h>
 #include <zlib.h>
 

@@ -202,7 +202,10 @@ int mdc_batch_cell(mdc_batch *b, int64_t row, int col, const char **p, uint32_t 
 /* Column as fixed-stride NUL-terminated slots, stride = max(cell length in the batch)+1 or
  * collen+1 when the schema has collen>0: the layout sqlstatement::bindin(pos,string&,len)
  * binds (public/db/oracle/_ooci.cpp:568-573), ready for an array bind.  Host memory owned
- * by the batch. */
+ * by the batch.  A cell longer than collen is cut to collen bytes in its slot: that happens only
+ * to a value carried over from an earlier, wider column (tools/xmltodb.cpp:494-518), where the
+ * reference assigns past the buffer it has bound (undefined there); the compact column
+ * (mdc_batch_host_column) keeps such a cell whole. */
 int mdc_batch_column_fixed(mdc_batch *b, int col, const char **base, size_t *stride);
 
 void mdc_batch_free(mdc_batch *b);

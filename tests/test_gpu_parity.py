@@ -1,5 +1,6 @@
 """GPU parity: the HIP path, called through the C ABI, against the CPU checker and the golden
 vectors.  Bit-exact for every output (cell bytes, offsets, record offsets, masks, typed values)."""
+import ctypes
 import os
 
 import numpy as np
@@ -514,3 +515,61 @@ def test_template_is_taken_from_another_record_when_the_second_is_the_odd_one(po
         assert left[1][0] <= 2 and left[2][0] <= 2, left  # another sample: only the odd record's tile does
     finally:
         p.close()
+
+
+@pytest.mark.parametrize("delta", [-3, 5])
+@pytest.mark.parametrize("full_write", [False, True])
+def test_write_pass_refuses_a_tile_the_sizing_pass_measured_differently(port, delta, full_write):
+    # The arenas are sized exactly by the sizing pass; the write pass measures every cell again with
+    # code of its own.  The host-side hook changes one counter between the passes, as a sizing pass
+    # that disagreed would have left it: the write pass must report an internal error (and store
+    # nothing beyond what was sized) instead of handing out a batch, and the parser must stay usable.
+    L = capi.lib()
+    L.mdc_internal_skew_counts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    if full_write:  # no room in the cell map: every tile goes through tile_kernel<true>
+        data = b"".join(b"%d,%d\n" % (i % 7, i % 3) for i in range(150000))
+        p = capi.Parser.csv(",", 2, typed=[schema.T_I64, schema.T_F64])
+        exp = port.parse_csv(data, ",", 2, typed=[schema.T_I64, schema.T_F64])
+        col = 1
+    else:
+        data, _ = gen.mind_xml(rows=2000)
+        p = capi.Parser.xml(schema.ZHOBTMIND)
+        p.parse_host(data).free()  # (sizes the cell map: the next parses take the emit kernel)
+        exp = port.parse_xml(data, schema.ZHOBTMIND)
+        col = 2
+    capi.check(L.mdc_internal_skew_counts(p.h, 1, col, delta))
+    with pytest.raises(capi.MdcError) as e:
+        p.parse_host(data)
+    assert e.value.code == capi.MDC_ERR_INTERNAL
+    if not full_write:
+        got = p.parse_host(data)
+        assert p.timing().full_write == 0
+        assert_batches_equal(got.to_host(), exp, "parse after a refused one")
+        got.free()
+    p.close()
+
+
+def test_bind_slabs_of_every_column_with_carried_values(port):
+    # mdc_batch_column_fixed for every column and row of records with missing tags, so that carried
+    # values (longer than the column's own collen in places) meet the slot size
+    recs = []
+    for i in range(700):
+        f = [b"<obtid>5%04d</obtid>" % i, b"<ddatetime>2024-05-19 16:%02d:00</ddatetime>" % (i % 60), b"<t>%d.%d</t>" % (i % 50, i % 10),
+             b"<p>1013.2</p>", b"<u>65</u>", b"<wd>180</wd>", b"<wf>3.4</wf>", b"<r>0.0</r>", b"<vis>10000.5</vis>",
+             b"<upttime>20240519162800</upttime>", b"<keyid>%d</keyid>" % (123456789012 + i)]
+        keep = [k for k in range(11) if (i * 7 + k * 3) % 5 != 0 or k == 0]
+        recs.append(b"".join(f[k] for k in keep) + b"<endl/>\n")
+    data = b"<data>\n" + b"".join(recs) + b"</data>\n"
+    p = capi.Parser.xml(schema.ZHOBTMIND)
+    b = p.parse_host(data)
+    exp = port.parse_xml(data, schema.ZHOBTMIND)
+    assert b.rows == exp.rows == 700
+    for c, col in enumerate(schema.ZHOBTMIND):
+        slab, stride = b.column_fixed(c)
+        assert stride == col.collen + 1
+        for r in range(exp.rows):
+            cell = exp.cell(r, c)[:col.collen]  # (a carried value is cut to the slot: see mdc_parse.h)
+            row = bytes(slab[r])
+            assert row[:len(cell)] == cell and row[len(cell):] == b"\0" * (stride - len(cell)), (r, c)
+    b.free()
+    p.close()
