@@ -36,7 +36,7 @@ MDC_F_NO_RECOFF = 1
 EXPORTS = [
     "mdc_version", "mdc_device_count", "mdc_strerror", "mdc_last_error",
     "mdc_parser_create_xml", "mdc_parser_create_csv", "mdc_parser_destroy",
-    "mdc_parse_device", "mdc_parse_host", "mdc_parse_file", "mdc_parser_last_timing",
+    "mdc_parse_device", "mdc_parse_host", "mdc_parse_file", "mdc_parse_device_noalloc", "mdc_parser_last_timing",
     "mdc_parse_xml_buffer", "mdc_parse_xml_file", "mdc_parse_csv_buffer",
     "mdc_stream_open", "mdc_stream_next", "mdc_stream_bytes", "mdc_stream_close",
     "mdc_batch_rows", "mdc_batch_ncols", "mdc_batch_words_per_row",

@@ -43,6 +43,8 @@ hipError_t launch_format(bool exact, const FormatParams &P, hipStream_t stream);
 hipError_t launch_timetostr(const int64_t *tv, uint64_t rows, const TimeFmt &F, int32_t tz_offset, uint32_t *off,
                             uint8_t *bytes, uint32_t *status, hipStream_t stream);
 uint32_t format_scan_parts(uint64_t rows);
+hipError_t noalloc_scratch_init(int device);
+void *noalloc_scratch_addr(int device);
 hipError_t launch_format_measure(const FormatParams &P, uint32_t *elen, uint64_t *reclen, uint64_t *part,
                                  uint64_t *recpos, hipStream_t stream);
 }  // namespace mdc
@@ -77,6 +79,7 @@ static int fail(int code, const char *fmt, ...) {
 // d_status: two status words, the diagnostic builds' counters from byte 16 on, and from u64
 // index REPORT_TOTALS on the totals that the scan writes for the host
 static const size_t REPORT_TOTALS = 32;
+static_assert(NOALLOC_SCRATCH_BYTES == MDC_NOALLOC_SCRATCH_BYTES, "the header states the size of the static scratch array");
 static const size_t STATUS_BYTES = (REPORT_TOTALS + MAX_COLS + 8) * 8;
 
 struct Device {
@@ -108,6 +111,9 @@ static int get_device(int id, Device **out) {
     Device *d = new Device();
     d->id = id;
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    // this device's copy of the static scratch array (mdc_parse_device_noalloc): its address is
+    // looked up here, once, while the device is current
+    HIP_TRY(noalloc_scratch_init(id));
     g_devices[id] = d;
     *out = d;
     return MDC_OK;
@@ -667,20 +673,59 @@ static int status_to_error(uint32_t st) {
     return MDC_OK;
 }
 
-extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc_batch **out) {
-    if (!p || !out) return fail(MDC_ERR_ARG, "NULL argument");
-    *out = nullptr;
-    if (n && !d_data) return fail(MDC_ERR_ARG, "d_data is NULL");
+// One parse of n device-resident bytes.  `ext` == nullptr: the outputs become a new batch (*out)
+// and the workspace is the parser's, grown on demand.  Otherwise (the entry point that allocates
+// nothing) the outputs are the caller's arrays, the workspace is carved out of this device's static
+// scratch array, no cell map is used (every tile takes the full write kernel), and the row count
+// and the columns' byte counts are returned through *rows_out / col_bytes.
+static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_outputs *ext, mdc_batch **out,
+                      int64_t *rows_out, uint64_t *col_bytes) {
     if ((uintptr_t)d_data & 15) return fail(MDC_ERR_ARG, "d_data must be 16-byte aligned");
     if (n >= ((size_t)1 << 40)) return fail(MDC_ERR_ARG, "input larger than 1 TiB");
     Device *d = p->dev;
     HIP_TRY(hipSetDevice(d->id));
     const uint32_t ncols = (uint32_t)p->ncols, ncnt = ncols + 1;
     const size_t ntiles = (n + TILE - 1) / TILE;
-    int rc = ensure_workspace(p, ntiles ? ntiles : 1);
-    if (rc) return rc;
-    rc = ensure_cellmap(p, n, ntiles);
-    if (rc) return rc;
+    uint32_t *d_counts, *d_hdr, *d_cellmap = nullptr;
+    uint64_t *d_base;
+    void *d_ptrs_ext = nullptr;
+    size_t map_cap = 0, map_stride = 0;
+    int rc;
+    if (ext) {
+        // tile headers | pointer table | prefixes, totals, segment totals | counters
+        const size_t nt = ntiles ? ntiles : 1;
+        size_t o = 0;
+        const size_t o_hdr = o;
+        o += (nt * 8 + 16 + 255) & ~(size_t)255;
+        const size_t o_ptrs = o;
+        o += (3 * (size_t)ncols * sizeof(void *) + 255) & ~(size_t)255;
+        const size_t o_base = o;
+        o += ((nt + 1 + scan_segments((uint32_t)nt)) * ncnt * 8 + 255) & ~(size_t)255;
+        const size_t o_counts = o;
+        o += nt * ncnt * 4;
+        if (o > NOALLOC_SCRATCH_BYTES)
+            return fail(MDC_ERR_TOO_LARGE,
+                        "an input of %zu bytes with %u columns needs %zu bytes of scratch; the static array holds %zu "
+                        "(use mdc_parse_device, or parse the input in parts)",
+                        n, ncols, o, (size_t)NOALLOC_SCRATCH_BYTES);
+        uint8_t *sc = (uint8_t *)noalloc_scratch_addr(d->id);
+        if (!sc) return fail(MDC_ERR_INTERNAL, "the static scratch array of device %d was never set up", d->id);
+        d_hdr = (uint32_t *)(sc + o_hdr);
+        d_ptrs_ext = sc + o_ptrs;
+        d_base = (uint64_t *)(sc + o_base);
+        d_counts = (uint32_t *)(sc + o_counts);
+    } else {
+        rc = ensure_workspace(p, ntiles ? ntiles : 1);
+        if (rc) return rc;
+        rc = ensure_cellmap(p, n, ntiles);
+        if (rc) return rc;
+        d_counts = p->d_counts;
+        d_base = p->d_base;
+        d_hdr = p->d_hdr;
+        d_cellmap = p->d_cellmap;
+        map_cap = p->map_cap;
+        map_stride = p->map_stride;
+    }
 
     TileParams P{};
     P.data = (const uint8_t *)d_data;
@@ -691,13 +736,13 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     P.words = p->words;
     P.p10_off = ((const SchemaHdr *)p->blob.data())->p10_off;
     P.ntiles = (uint32_t)ntiles;
-    P.tile_counts = p->d_counts;
-    P.tile_base = p->d_base;
+    P.tile_counts = d_counts;
+    P.tile_base = d_base;
     P.status = p->d_status;
-    P.cellmap = p->map_stride ? p->d_cellmap : nullptr;
-    P.map_cap = (uint32_t)p->map_cap;
-    P.map_stride = (uint32_t)p->map_stride;
-    P.tile_hdr = p->d_hdr;
+    P.cellmap = map_stride ? d_cellmap : nullptr;
+    P.map_cap = (uint32_t)map_cap;
+    P.map_stride = (uint32_t)map_stride;
+    P.tile_hdr = d_hdr;
     P.tmpl = p->d_tmpl;
     P.use_tmpl = p->mode == MODE_XML ? 1u : 0u;
     P.tmpl_sample = p->tmpl_sample;
@@ -722,7 +767,7 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
         if (build_tmpl) HIP_TRY(launch_template_kernel(P, s));
         HIP_TRY(launch_tile_kernel(false, P, s));
         if (p->skew_tile >= 0 && (size_t)p->skew_tile < ntiles && p->skew_col >= 0 && p->skew_col < (int)ncols) {
-            uint32_t *w = p->d_counts + (size_t)p->skew_tile * ncnt + p->skew_col, v = 0;
+            uint32_t *w = d_counts + (size_t)p->skew_tile * ncnt + p->skew_col, v = 0;
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipMemcpy(&v, w, 4, hipMemcpyDeviceToHost));
             v += (uint32_t)p->skew_delta;
@@ -730,7 +775,7 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
             p->skew_tile = -1;
         }
         HIP_TRY(hipEventRecord(p->ev[1], s));
-        HIP_TRY(launch_scan_tiles(p->d_counts, p->d_base, (uint32_t)ntiles, ncnt, (uint64_t *)p->d_status + REPORT_TOTALS, s));
+        HIP_TRY(launch_scan_tiles(d_counts, d_base, (uint32_t)ntiles, ncnt, (uint64_t *)p->d_status + REPORT_TOTALS, s));
         HIP_TRY(hipEventRecord(p->ev[2], s));
         // status words and totals with one copy
         HIP_TRY(hipMemcpyAsync(p->h_report, p->d_status, (REPORT_TOTALS + ncnt) * 8, hipMemcpyDeviceToHost, s));
@@ -767,27 +812,52 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
             return fail(MDC_ERR_TOO_LARGE, "column %u holds %llu bytes; split the input", c,
                         (unsigned long long)p->h_totals[c]);
 
-    mdc_batch *b = new mdc_batch();
-    b->dev = d;
-    b->rows = (int64_t)rows;
-    b->ncols = (int)ncols;
-    b->words = p->words;
-    b->typed = p->typed;
-    for (auto &c : p->cols) b->collen.push_back(c.collen);
-    b->d_off.assign(ncols, nullptr);
-    b->d_bytes.assign(ncols, nullptr);
-    b->d_val.assign(ncols, nullptr);
-    b->nbytes.assign(ncols, 0);
-    b->h_off.resize(ncols);
-    b->h_bytes.resize(ncols);
-    b->h_val.resize(ncols);
-    b->have_col.assign(ncols, false);
-    b->have_val.assign(ncols, false);
-    b->h_fixed.resize(ncols);
-    b->fixed_stride.assign(ncols, 0);
     uint64_t bytes_out = 0;
-    auto A = [&](size_t bytes, void **q) { return dev_alloc(d, bytes, q); };
-    void *q = nullptr;
+    mdc_batch *b = nullptr;
+    uint64_t *o_rec_off = nullptr;
+    uint32_t *o_valid = nullptr, *o_found = nullptr;
+    void *d_ptrs = nullptr;
+    void **hp = p->h_ptrs;  // the pointer table on its way to the device: off[], bytes[], val[]
+    if (ext) {
+        // the caller's arrays must hold what the sizing pass counted
+        if ((int64_t)rows > ext->rows_cap)
+            return fail(MDC_ERR_TOO_LARGE, "%llu records, the output arrays hold %lld", (unsigned long long)rows,
+                        (long long)ext->rows_cap);
+        for (uint32_t c = 0; c < ncols; ++c) {
+            if (p->h_totals[c] > ext->cols[c].bytes_cap)
+                return fail(MDC_ERR_TOO_LARGE, "column %u holds %llu bytes, its output array %llu", c,
+                            (unsigned long long)p->h_totals[c], (unsigned long long)ext->cols[c].bytes_cap);
+            hp[c] = ext->cols[c].d_off;
+            hp[ncols + c] = ext->cols[c].d_bytes;
+            hp[2 * ncols + c] = p->typed[c] != MDC_T_NONE ? ext->cols[c].d_val : nullptr;
+            bytes_out += (rows + 1) * 4 + p->h_totals[c] + (p->typed[c] != MDC_T_NONE ? rows * 8 : 0);
+        }
+        o_rec_off = (p->flags & MDC_F_NO_RECOFF) ? nullptr : ext->d_rec_off;
+        if (o_rec_off) bytes_out += (rows + 1) * 8;
+        o_valid = ext->d_valid;
+        o_found = ext->d_found;
+        d_ptrs = d_ptrs_ext;
+    } else {
+        b = new mdc_batch();
+        b->dev = d;
+        b->rows = (int64_t)rows;
+        b->ncols = (int)ncols;
+        b->words = p->words;
+        b->typed = p->typed;
+        for (auto &c : p->cols) b->collen.push_back(c.collen);
+        b->d_off.assign(ncols, nullptr);
+        b->d_bytes.assign(ncols, nullptr);
+        b->d_val.assign(ncols, nullptr);
+        b->nbytes.assign(ncols, 0);
+        b->h_off.resize(ncols);
+        b->h_bytes.resize(ncols);
+        b->h_val.resize(ncols);
+        b->have_col.assign(ncols, false);
+        b->have_val.assign(ncols, false);
+        b->h_fixed.resize(ncols);
+        b->fixed_stride.assign(ncols, 0);
+        auto A = [&](size_t bytes, void **q) { return dev_alloc(d, bytes, q); };
+        void *q = nullptr;
 #define ALLOC_OR_FAIL(bytes, dst, T)     \
     do {                                 \
         rc = A((bytes), &q);             \
@@ -797,24 +867,35 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
         }                                \
         dst = (T)q;                      \
     } while (0)
-    if (!(p->flags & MDC_F_NO_RECOFF)) {
-        ALLOC_OR_FAIL((rows + 1) * 8, b->d_rec_off, uint64_t *);
-        bytes_out += (rows + 1) * 8;
-    }
-    for (uint32_t c = 0; c < ncols; ++c) {
-        b->nbytes[c] = p->h_totals[c];
-        ALLOC_OR_FAIL((rows + 1) * 4, b->d_off[c], uint32_t *);
-        ALLOC_OR_FAIL(b->nbytes[c] + 16, b->d_bytes[c], uint8_t *);
-        bytes_out += (rows + 1) * 4 + b->nbytes[c];
-        if (p->typed[c] != MDC_T_NONE) {
-            ALLOC_OR_FAIL(rows * 8 + 8, b->d_val[c], uint64_t *);
-            bytes_out += rows * 8;
+        if (!(p->flags & MDC_F_NO_RECOFF)) {
+            ALLOC_OR_FAIL((rows + 1) * 8, b->d_rec_off, uint64_t *);
+            bytes_out += (rows + 1) * 8;
         }
+        for (uint32_t c = 0; c < ncols; ++c) {
+            b->nbytes[c] = p->h_totals[c];
+            ALLOC_OR_FAIL((rows + 1) * 4, b->d_off[c], uint32_t *);
+            ALLOC_OR_FAIL(b->nbytes[c] + 16, b->d_bytes[c], uint8_t *);
+            bytes_out += (rows + 1) * 4 + b->nbytes[c];
+            if (p->typed[c] != MDC_T_NONE) {
+                ALLOC_OR_FAIL(rows * 8 + 8, b->d_val[c], uint64_t *);
+                bytes_out += rows * 8;
+            }
+        }
+        ALLOC_OR_FAIL(rows * p->words * 4 + 4, b->d_valid, uint32_t *);
+        ALLOC_OR_FAIL(rows * p->words * 4 + 4, b->d_found, uint32_t *);
+        ALLOC_OR_FAIL(3 * (size_t)ncols * sizeof(void *), b->d_ptrs, void *);
+#undef ALLOC_OR_FAIL
+        for (uint32_t c = 0; c < ncols; ++c) {
+            hp[c] = b->d_off[c];
+            hp[ncols + c] = b->d_bytes[c];
+            hp[2 * ncols + c] = b->d_val[c];
+        }
+        o_rec_off = b->d_rec_off;
+        o_valid = b->d_valid;
+        o_found = b->d_found;
+        d_ptrs = b->d_ptrs;
     }
-    ALLOC_OR_FAIL(rows * p->words * 4 + 4, b->d_valid, uint32_t *);
-    ALLOC_OR_FAIL(rows * p->words * 4 + 4, b->d_found, uint32_t *);
     bytes_out += 2 * rows * p->words * 4;
-    ALLOC_OR_FAIL(3 * (size_t)ncols * sizeof(void *), b->d_ptrs, void *);
     // from here on a failed runtime call gives the half-built batch back before it returns
 #define HIP_TRY_B(expr)                                                                \
     do {                                                                               \
@@ -824,27 +905,19 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
             return fail(MDC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));          \
         }                                                                              \
     } while (0)
-    {
-        // (from pinned memory that lives until the parser's next call: no wait for the copy here)
-        void **hp = p->h_ptrs;
-        for (uint32_t c = 0; c < ncols; ++c) {
-            hp[c] = b->d_off[c];
-            hp[ncols + c] = b->d_bytes[c];
-            hp[2 * ncols + c] = b->d_val[c];
-        }
-        HIP_TRY_B(hipMemcpyAsync(b->d_ptrs, hp, 3 * (size_t)ncols * sizeof(void *), hipMemcpyHostToDevice, s));
-    }
+    // (from pinned memory that lives until the parser's next call: no wait for the copy here)
+    HIP_TRY_B(hipMemcpyAsync(d_ptrs, hp, 3 * (size_t)ncols * sizeof(void *), hipMemcpyHostToDevice, s));
     if (ntiles == 0) {
         // nothing to launch: every offset array is the single entry 0
-        for (uint32_t c = 0; c < ncols; ++c) HIP_TRY_B(hipMemsetAsync(b->d_off[c], 0, 4, s));
-        if (b->d_rec_off) HIP_TRY_B(hipMemsetAsync(b->d_rec_off, 0, 8, s));
+        for (uint32_t c = 0; c < ncols; ++c) HIP_TRY_B(hipMemsetAsync(hp[c], 0, 4, s));
+        if (o_rec_off) HIP_TRY_B(hipMemsetAsync(o_rec_off, 0, 8, s));
     }
-    P.rec_off = b->d_rec_off;
-    P.off = (uint32_t *const *)b->d_ptrs;
-    P.bytes = (uint8_t *const *)((void **)b->d_ptrs + ncols);
-    P.val = (uint64_t *const *)((void **)b->d_ptrs + 2 * ncols);
-    P.valid = b->d_valid;
-    P.found = b->d_found;
+    P.rec_off = o_rec_off;
+    P.off = (uint32_t *const *)d_ptrs;
+    P.bytes = (uint8_t *const *)((void **)d_ptrs + ncols);
+    P.val = (uint64_t *const *)((void **)d_ptrs + 2 * ncols);
+    P.valid = o_valid;
+    P.found = o_found;
     HIP_TRY_B(hipEventRecord(p->ev[2], s));
     // tiles with a complete cell map take the short write kernel, the others the full one
     P.L = p->LEs[p->lb_level];
@@ -860,16 +933,12 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     }
     HIP_TRY_B(hipEventRecord(p->ev[3], s));
     HIP_TRY_B(hipMemcpyAsync(p->h_report, p->d_status, 4, hipMemcpyDeviceToHost, s));
-    hipError_t se = hipStreamSynchronize(s);
-    if (se != hipSuccess) {
-        batch_release(b);
-        return fail(MDC_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(se));
-    }
+    HIP_TRY_B(hipStreamSynchronize(s));
+#undef HIP_TRY_B
     uint32_t st = (uint32_t)p->h_report[0] & ~ST_UNMAPPED;
     if (st & ST_NUMERIC_RANGE) {
         // some floating-point texts need the multi-precision stage
-        le = launch_long_float((const uint8_t *)p->d_blob, P.off, P.bytes, P.val, b->d_valid, b->d_found, rows, ncols,
-                               s);
+        le = launch_long_float((const uint8_t *)p->d_blob, P.off, P.bytes, P.val, o_valid, o_found, rows, ncols, s);
         if (le == hipSuccess) le = hipStreamSynchronize(s);
         if (le != hipSuccess) {
             batch_release(b);
@@ -889,8 +958,34 @@ extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc
     t.rows = (int64_t)rows;
     t.tiles = (int)ntiles;
     t.full_write = unmapped ? 1 : 0;
-    *out = b;
+    if (out) *out = b;
+    if (rows_out) *rows_out = (int64_t)rows;
+    if (col_bytes)
+        for (uint32_t c = 0; c < ncols; ++c) col_bytes[c] = p->h_totals[c];
     return MDC_OK;
+}
+
+extern "C" int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc_batch **out) {
+    if (!p || !out) return fail(MDC_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    if (n && !d_data) return fail(MDC_ERR_ARG, "d_data is NULL");
+    return parse_impl(p, d_data, n, nullptr, out, nullptr, nullptr);
+}
+
+extern "C" int mdc_parse_device_noalloc(mdc_parser *p, const void *d_data, size_t n, const mdc_outputs *o, int64_t *rows,
+                                        uint64_t *col_bytes) {
+    if (!p || !o || !rows) return fail(MDC_ERR_ARG, "NULL argument");
+    if (n && !d_data) return fail(MDC_ERR_ARG, "d_data is NULL");
+    if (o->rows_cap < 0 || !o->cols || !o->d_valid || !o->d_found) return fail(MDC_ERR_ARG, "incomplete output description");
+    for (int c = 0; c < p->ncols; ++c) {
+        if (!o->cols[c].d_off || !o->cols[c].d_bytes) return fail(MDC_ERR_ARG, "column %d: NULL output array", c);
+        if (p->typed[c] != MDC_T_NONE && !o->cols[c].d_val) return fail(MDC_ERR_ARG, "column %d: typed, but no value array", c);
+        if (((uintptr_t)o->cols[c].d_off & 3) || ((uintptr_t)o->cols[c].d_val & 7))
+            return fail(MDC_ERR_ARG, "column %d: misaligned output array", c);
+    }
+    if (((uintptr_t)o->d_valid & 3) || ((uintptr_t)o->d_found & 3) || ((uintptr_t)o->d_rec_off & 7))
+        return fail(MDC_ERR_ARG, "misaligned output array");
+    return parse_impl(p, d_data, n, o, nullptr, rows, col_bytes);
 }
 
 extern "C" int mdc_parse_host(mdc_parser *p, const void *h_data, size_t n, mdc_batch **out) {

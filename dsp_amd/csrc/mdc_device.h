@@ -1,6 +1,7 @@
 // mdc_device.h -- structures shared by the host side (mdc_abi.cpp) and the gfx950 kernels
 // (mdc_kernels.hip).  Everything here is plain data laid out identically on both sides.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace mdc {
@@ -21,6 +22,7 @@ constexpr int MAX_COLS = 128;
 constexpr int MAX_ENDBZ = 32;
 constexpr int MAX_SEP = 16;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)2 << 20;  // static device scratch of mdc_parse_device_noalloc
 // Tag template (tagged input): the '<' events of one sample record, in order.  Event k of a
 // record whose events all repeat the sample's tag texts byte for byte matches what sample event
 // k matched, so such a record needs no table lookup.  In memory: 4 words of header (word 0 =

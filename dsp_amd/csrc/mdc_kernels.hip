@@ -2422,6 +2422,31 @@ hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t nt
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// Scratch of the entry point that allocates nothing (mdc_parse_device_noalloc): the per-tile
+// counters, their prefixes, the tile headers and the table of output pointers, which the
+// allocating entry points keep in device memory of the parser.  Every GPU the library runs on
+// holds its own copy of the array until the process ends, at an address of its own: the array's
+// name is only a handle for hipGetSymbolAddress, and host code uses the address that call gave
+// for the device in question, never the name.
+static __device__ __align__(256) uint8_t scratch[NOALLOC_SCRATCH_BYTES];
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static void *g_scratch_addr[SCRATCH_MAX_DEVICES];
+
+// Once per device, with that device current (the library does it when it first uses a device).
+hipError_t noalloc_scratch_init(int device) {
+    if (device < 0 || device >= SCRATCH_MAX_DEVICES) return hipErrorInvalidDevice;
+    void *ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    g_scratch_addr[device] = ptr;
+    return hipSuccess;
+}
+// this device's copy of the array (nullptr: the device was never set up)
+void *noalloc_scratch_addr(int device) {
+    return device >= 0 && device < SCRATCH_MAX_DEVICES ? g_scratch_addr[device] : nullptr;
+}
+
 hipError_t launch_fixed_stride(const uint32_t *off, const uint8_t *bytes, uint8_t *slab, uint64_t rows,
                                uint32_t stride, hipStream_t stream) {
     if (rows == 0) return hipSuccess;

@@ -149,6 +149,43 @@ int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc_batch **ou
 int mdc_parse_host(mdc_parser *p, const void *h_data, size_t n, mdc_batch **out);
 /* Parse a whole file; MDC_FILE_OPEN_FAILED (5) when it cannot be opened. */
 int mdc_parse_file(mdc_parser *p, const char *path, mdc_batch **out);
+/* The same parse as mdc_parse_device for callers that cannot allocate device memory (code under
+ * HIP graph capture set-up, tight serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  The call itself allocates and frees nothing on the device: the
+ * outputs are arrays the caller made beforehand (device memory of the parser's GPU), and the
+ * library's own workspace (per-tile counters, their prefixes, tile headers, the table of output
+ * pointers) lies in a static device array of MDC_NOALLOC_SCRATCH_BYTES that every GPU the
+ * library runs on holds until the process ends.
+ *   limit    tiles x (columns + 1) x 12 bytes and some headers must fit the array: about
+ *            215 MiB of input with 11 columns, 20 MiB with 128; beyond that MDC_ERR_TOO_LARGE
+ *            (use mdc_parse_device, or parse the input in parts)
+ *   outputs  per column: rows_cap + 1 u32 offsets, bytes_cap bytes of cells, and for a typed
+ *            column rows_cap u64 values; rows_cap x mdc_batch_words_per_row words each of valid
+ *            and found bits; optionally rows_cap + 1 u64 record offsets (d_rec_off NULL: none).
+ *            More records than rows_cap, or a column with more bytes than its bytes_cap, gives
+ *            MDC_ERR_TOO_LARGE before anything is written to the outputs
+ *   results  *rows = records parsed; col_bytes (may be NULL) receives the ncols byte counts.
+ *            The arrays hold what the batch of mdc_parse_device would hold, bit for bit
+ *   sharing  every call on one GPU uses that GPU's one scratch array: calls that overlap on a GPU
+ *            (two threads, two parsers) race; calls on different GPUs do not.  Nothing in the
+ *            array needs clearing between calls (a call writes every word it later reads)
+ * It is the slower of the two entry points (no cell map is kept between the two passes). */
+typedef struct mdc_out_col {
+    uint32_t *d_off;
+    uint8_t *d_bytes;
+    uint64_t bytes_cap;
+    uint64_t *d_val; /* typed columns only */
+} mdc_out_col;
+typedef struct mdc_outputs {
+    int64_t rows_cap;
+    const mdc_out_col *cols; /* one per column of the parser's schema */
+    uint32_t *d_valid;
+    uint32_t *d_found;
+    uint64_t *d_rec_off; /* may be NULL */
+} mdc_outputs;
+#define MDC_NOALLOC_SCRATCH_BYTES (2u << 20)
+int mdc_parse_device_noalloc(mdc_parser *p, const void *d_data, size_t n, const mdc_outputs *o, int64_t *rows,
+                             uint64_t *col_bytes);
 /* timings of the most recent successful parse on this parser */
 int mdc_parser_last_timing(const mdc_parser *p, mdc_timing *t);
 
