@@ -9,17 +9,32 @@ configuration the metric is quoted on; with N>1 every rank parses its own 1 GiB 
 own GPU (files shard independently: no data-path collective, only the row counts and timings
 are gathered on the host over gloo).  Rank 0 prints one JSON line.
 
+Started without WORLD_SIZE and with --gpus N > 1, this script starts the N ranks itself (fresh
+child processes, before anything here has touched the GPU); under torch.distributed.run it is one
+of the ranks.
+
 `value` is input GB/s over all ranks (bytes consumed / max-over-ranks wall time of the K
-steps).  `roofline` prices the dominant kernel (the tile kernel in write mode) with HIP-event
-durations taken inside the library on the stream it launches on; `cpu_baseline` times the CPU
-checker (the reference's own code when oracle/_ref was built, else the C restatement) on a
-bounded sample of the same bytes, single-threaded as the reference runs.
+steps).  `roofline` prices the dominant kernel (the write pass) with HIP-event durations taken
+inside the library on the stream it launches on; `cpu_baseline` times the CPU checker (the
+reference's own code when oracle/_ref was built, else the C restatement) on a bounded sample of
+the same bytes, single-threaded as the reference runs.  Beside the headline, in the same line:
+
+  archive    the file-sharded path (BASELINE config 4 in small): every rank streams its share of
+             a sorted list of 128 MiB files through mdc_stream_* (read into pinned memory, upload
+             on a copy stream beside the parse); end-to-end GB/s over all ranks, row totals
+  e2e        (N=1) end-to-end rates that include the way into HBM: a host buffer (PCIe copy
+             included), plain files, gzip files with 1 and 16 inflating threads
+  delimited  (N=1) the 4 GiB ccmdstr-split configuration with a roofline of its own
 """
 import argparse
 import ctypes
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,7 +42,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from dsp_amd import capi, gen, schema  # noqa: E402  (loads the HIP library before anything else)
+from dsp_amd import archive, capi, gen, schema  # noqa: E402  (nothing here touches the GPU at import)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec
 
@@ -44,8 +59,44 @@ def parse_args():
     ap.add_argument("--cpu-procs", type=int, default=16,
                     help="processes of the all-cores CPU baseline (one 64 MiB batch each); 0 disables it")
     ap.add_argument("--verify", type=int, default=1, help="check a slice of the output against the CPU checker")
+    ap.add_argument("--archive-files-per-gpu", type=int, default=8, help="0 disables the file-sharded section")
+    ap.add_argument("--archive-file-mb", type=int, default=128)
+    ap.add_argument("--archive-threads", type=int, default=4, help="host threads reading ahead per rank")
+    ap.add_argument("--archive-dir", default="", help="where the files are written (default: a temp dir in /dev/shm)")
+    ap.add_argument("--e2e", type=int, default=1, help="N=1: host-buffer, plain-file and gzip end-to-end rates")
+    ap.add_argument("--delimited-gb", type=float, default=4.0,
+                    help="N=1, xml workload: size in GiB of the delimited configuration's batch; 0 disables the section")
     return ap.parse_args()
 
+
+# ---------------------------------------------------------------------------------------------
+# N > 1 without a launcher: this process only starts the ranks
+
+def launch_ranks(a):
+    """Starts a.gpus rank processes of this script (one GPU each through LOCAL_RANK) and passes
+    rank 0's line through.  Called before anything in this process has touched the GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    tmp = a.archive_dir or tempfile.mkdtemp(prefix="mdc_arch_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MDC_BENCH_ARCHIVE_DIR=tmp)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    if not a.archive_dir:
+        shutil.rmtree(tmp, ignore_errors=True)
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
 
 def make_parser(workload, device):
     if workload == "xml":
@@ -57,7 +108,20 @@ def make_data(workload, nbytes, rank):
     first = rank * 10_000_000
     if workload == "xml":
         return gen.mind_xml(nbytes=nbytes, first_row=first)
-    return gen.mind_csv(nbytes=nbytes, first_row=first)
+    return big_csv(nbytes, first)
+
+
+def big_csv(nbytes, first_row=0, part=256 << 20):
+    """A delimited batch of about nbytes, generated in parts by threads (the generator is C code
+    that runs without the interpreter lock) and joined."""
+    from concurrent.futures import ThreadPoolExecutor
+    nparts = max(1, (nbytes + part - 1) // part)
+    sizes = [min(part, nbytes - i * part) for i in range(nparts)]
+    with ThreadPoolExecutor(max_workers=min(16, nparts)) as ex:
+        made = list(ex.map(lambda i: gen.mind_csv(nbytes=sizes[i], first_row=first_row + i * 5_000_000), range(nparts)))
+    if nparts == 1:
+        return made[0]
+    return np.concatenate([m[0] for m in made]), sum(m[1] for m in made)
 
 
 def cpu_baseline(workload, data, sample_mb):
@@ -86,7 +150,6 @@ def cpu_baseline_all_cores(workload, procs):
     """How the reference scales in deployment: one single-threaded process per share of the
     files.  `procs` worker processes (tools/cpu_slice.py), each with a 64 MiB batch of its own,
     started together; the rate is all their bytes over the slowest one's time."""
-    import subprocess
     procs = max(1, min(procs, os.cpu_count() or 1))
     cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_slice.py"), workload, str(64 << 20)]
     ps = [subprocess.Popen(cmd + [str(20_000_000 + 1_000_000 * i)], stdout=subprocess.PIPE, text=True) for i in range(procs)]
@@ -109,7 +172,6 @@ def copy_ceiling(device, src_ptr, nbytes, repeats=10):
     batch (one byte read and one written per byte, the mix closest to the write kernel's), timed
     with HIP events on the null stream; GB/s read + written.  None when the runtime library cannot
     be reached from here."""
-    import ctypes
     try:
         hip = ctypes.CDLL("libamdhip64.so")
     except OSError:
@@ -158,20 +220,188 @@ def measured_traffic(kernel, nbytes):
     return int(t["traffic_bytes"])
 
 
+def timed_steps(parser, dbuf, steps, warmup, barrier):
+    """W untimed parses, then exactly K timed ones between two barriers.  Returns wall seconds, the
+    summed HIP-event phase times, rows, output bytes."""
+    def step():
+        b = parser.parse_device(dbuf.ptr, dbuf.n)
+        rows = b.rows
+        t = parser.timing()
+        b.free()
+        return rows, t
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    acc = {"count": 0.0, "scan": 0.0, "write": 0.0, "total": 0.0}
+    rows, bytes_out = 0, 0
+    for _ in range(steps):
+        rows, t = step()
+        acc["count"] += t.count_ms
+        acc["scan"] += t.scan_ms
+        acc["write"] += t.write_ms
+        acc["total"] += t.total_ms
+        bytes_out = t.bytes_out
+    capi.check(capi.lib().mdc_device_synchronize(dbuf.device))
+    local_s = time.perf_counter() - t0
+    barrier()
+    return local_s, acc, rows, bytes_out
+
+
+def roofline_of(kernel, nbytes, bytes_out, write_ms, traffic):
+    alg_bytes = nbytes + bytes_out
+    achieved = alg_bytes / (write_ms * 1e-3) / 1e9
+    return {
+        "bound": "hbm", "kernel": kernel,
+        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 4),
+        "traffic": traffic,
+        "algorithmic_bytes_per_launch": int(alg_bytes),
+        "avg_launch_ms": round(write_ms, 4),
+    }
+
+
+def verify_prefix(parser, dbuf, data, workload):
+    """The first 8 MiB of the batch, cell for cell, against the CPU checker."""
+    from oracle import oracle_lib
+    chk = oracle_lib.load("port")
+    cut = int(np.flatnonzero(data[: 8 << 20] == 10)[-1]) + 1
+    if workload == "xml":
+        exp = chk.parse_xml(np.ascontiguousarray(data[:cut]), schema.ZHOBTMIND)
+    else:
+        exp = chk.parse_csv(np.ascontiguousarray(data[:cut]), ",", 10, typed=schema.MIND_CSV_TYPED)
+    b = parser.parse_device(dbuf.ptr, dbuf.n)
+    ok = True
+    n = exp.rows
+    for c in range(exp.ncols):
+        off, dat = b.column(c)
+        ok &= bool(np.array_equal(off[: n + 1], exp.off[c]))
+        ok &= bool(np.array_equal(dat[: int(exp.off[c][n])], exp.data[c]))
+        if exp.val[c] is not None:
+            ok &= bool(np.array_equal(b.values(c)[:n], exp.val[c]))
+    b.free()
+    if not ok:
+        raise SystemExit("GPU output differs from the CPU checker: refusing to report a number")
+    return int(n)
+
+
+def archive_section(a, parser, rank, world, barrier, reduce_sum, reduce_max, files):
+    """Every rank has written the files of its share (deterministic: file i is the same bytes
+    whoever writes it); all ranks stream their shares between two barriers."""
+    nfiles = a.archive_files_per_gpu * world
+    paths, rows_exp, nbytes = files
+    parser.parse_file(paths[0]).free()  # pinned buffers and device workspace sized for these files
+    barrier()
+    res = archive.run_share(parser, paths, threads=a.archive_threads)
+    barrier()
+    for p in paths:
+        os.remove(p)
+    if res.errors or res.rows_per_file != rows_exp:
+        raise SystemExit(f"archive share of rank {rank}: rows per file differ from the generator's ({res.errors[:2]})")
+    tot = reduce_sum([float(res.rows), float(sum(nbytes)), float(len(paths))])
+    slowest = reduce_max(res.seconds)
+    return {
+        "workload": f"{nfiles} files of {a.archive_file_mb} MiB ZHOBTMIND XML in sorted order, dealt round-robin to {world} rank(s), "
+                    "each share through mdc_stream (page cache -> pinned -> HBM -> columns)",
+        "files": int(tot[2]), "bytes": int(tot[1]), "rows": int(tot[0]), "rows_match_generator": True,
+        "threads_per_rank": a.archive_threads, "seconds": round(slowest, 4),
+        "GBps_end_to_end": round(tot[1] / slowest / 1e9, 3), "records_per_s": round(tot[0] / slowest, 1),
+    }
+
+
+def e2e_section(a, parser, data, gz_files):
+    """N=1: what the way into HBM costs.  Never the headline."""
+    out = {}
+    parser.parse_host(data[: 64 << 20]).free()
+    t0 = time.perf_counter()
+    b = parser.parse_host(data)
+    dt = time.perf_counter() - t0
+    b.free()
+    out["host_buffer_GBps"] = round(len(data) / dt / 1e9, 3)  # pageable source, PCIe copy included
+    paths, rows_exp, nbytes = gz_files
+    for threads in (1, 16):
+        res = archive.run_share(parser, paths, threads=threads)
+        if res.errors or res.rows_per_file != rows_exp:
+            raise SystemExit("gzip stream: rows differ from the generator's")
+        out[f"gzip_stream_GBps_{threads}_threads"] = round(sum(nbytes) / res.seconds / 1e9, 3)
+    out["gzip_sample"] = f"16 files of 32 MiB, gzip -6 ({sum(os.path.getsize(p) for p in paths) >> 20} MiB compressed), inflated by host threads (zlib)"
+    for p in paths:
+        os.remove(p)
+    return out
+
+
+def delimited_section(a, device):
+    """N=1: BASELINE's delimited configuration (ccmdstr split, 10 fields, 7 doubles and a long)."""
+    nbytes = int(a.delimited_gb * (1 << 30))
+    data, _ = big_csv(nbytes)
+    parser = make_parser("csv", device)
+    dbuf = capi.DeviceBuffer(data, device)
+    sync = lambda: capi.check(capi.lib().mdc_device_synchronize(device))  # noqa: E731
+    steps, warmup = 10, 5
+    local_s, acc, rows, bytes_out = timed_steps(parser, dbuf, steps, warmup, sync)
+    verified = verify_prefix(parser, dbuf, data, "csv")
+    sec = {
+        "config": {"workload": "%.3g GiB synthetic ZHOBTMIND delimited batch, ccmdstr split -> 10 fields" % (dbuf.n / 2**30),
+                   "bytes": dbuf.n, "records": rows},
+        "value": round(dbuf.n * steps / local_s / 1e9, 3), "unit": "GB/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": round(local_s / steps * 1e3, 4), "records_per_s": round(rows * steps / local_s, 1),
+        "roofline": roofline_of("mdc::emit_kernel (write pass)", dbuf.n, bytes_out, acc["write"] / steps, None),
+        "kernel_ms": {"sizing_pass": round(acc["count"] / steps, 4), "scan": round(acc["scan"] / steps, 4),
+                      "write_pass": round(acc["write"] / steps, 4), "device_total": round(acc["total"] / steps, 4)},
+        "hbm_frac_whole_parse": round((dbuf.n + bytes_out) / (acc["total"] / steps * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "verified_records": verified,
+    }
+    dbuf.free()
+    parser.close()
+    return sec
+
+
 def main():
     a = parse_args()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(launch_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
+        import torch
         import torch.distributed as dist  # gloo on host tensors only: timings and row counts
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        import torch
+    # The files of the file-sharded sections are written first, by worker processes, while this
+    # process has not touched the GPU yet (no fork of a process that holds a HIP context).
+    arch_files = gz_files = base_dir = own_dir = None
+    if a.archive_files_per_gpu > 0 and a.workload == "xml":
+        base_dir = os.environ.get("MDC_BENCH_ARCHIVE_DIR") or a.archive_dir
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        if not base_dir:
+            if world > 1:  # (under an external launcher the ranks agree on a place by its port)
+                base_dir = os.path.join(shm or tempfile.gettempdir(), "mdc_arch_%s" % os.environ.get("MASTER_PORT", "0"))
+            else:
+                base_dir = own_dir = tempfile.mkdtemp(prefix="mdc_arch_", dir=shm)
+        mine = archive.rank_share(a.archive_files_per_gpu * world, rank, world)
+        arch_files = archive.make_files(base_dir, mine, a.archive_file_mb << 20, workers=8)
+        if a.e2e and world == 1:
+            gz_files = archive.make_files(base_dir, range(900, 916), 32 << 20, gz=True, workers=8)
     ndev = capi.lib().mdc_device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU: the parsing path exists only as gfx950 code")
     device = local_rank % ndev
+
+    def reduce_sum(vals):
+        if dist is None:
+            return list(vals)
+        t = torch.tensor(list(vals), dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.tolist()
+
+    def reduce_max(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
 
     data, rows_gen = make_data(a.workload, a.bytes, rank)
     parser = make_parser(a.workload, device)
@@ -183,45 +413,26 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def step():
-        b = parser.parse_device(dbuf.ptr, dbuf.n)
-        rows = b.rows
-        t = parser.timing()
-        b.free()
-        return rows, t
+    local_s, acc, rows, bytes_out = timed_steps(parser, dbuf, a.steps, a.warmup, barrier)
+    elapsed = reduce_max(local_s)
+    total_bytes, total_rows = reduce_sum([float(dbuf.n), float(rows)])
 
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    acc = {"count": 0.0, "scan": 0.0, "write": 0.0, "total": 0.0}
-    rows = 0
-    for _ in range(a.steps):
-        rows, t = step()
-        acc["count"] += t.count_ms
-        acc["scan"] += t.scan_ms
-        acc["write"] += t.write_ms
-        acc["total"] += t.total_ms
-        bytes_out = t.bytes_out
-    capi.check(L.mdc_device_synchronize(device))
-    local_s = time.perf_counter() - t0
-    barrier()
-    elapsed = local_s
-    total_bytes = float(dbuf.n)
-    total_rows = float(rows)
-    if dist is not None:
-        tt = torch.tensor([local_s], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
-        cnt = torch.tensor([float(dbuf.n), float(rows)], dtype=torch.float64)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_bytes, total_rows = float(cnt[0]), float(cnt[1])
+    arch = e2e = None
+    if arch_files is not None:
+        arch = archive_section(a, parser, rank, world, barrier, reduce_sum, reduce_max, arch_files)
+        if gz_files is not None:
+            e2e = e2e_section(a, parser, data, gz_files)
+        if own_dir:
+            shutil.rmtree(own_dir, ignore_errors=True)
+        elif world > 1 and not (os.environ.get("MDC_BENCH_ARCHIVE_DIR") or a.archive_dir):
+            barrier()
+            if rank == 0:
+                shutil.rmtree(base_dir, ignore_errors=True)
 
     if rank == 0:
         k = a.steps
         write_ms = acc["write"] / k
         alg_bytes = dbuf.n + bytes_out
-        achieved = alg_bytes / (write_ms * 1e-3) / 1e9
         out = {
             "metric": "obs_%s_parsed_to_columns_GBps" % a.workload,
             "value": round(total_bytes * k / elapsed / 1e9, 3),
@@ -242,14 +453,8 @@ def main():
                 "bytes_per_gpu": dbuf.n, "records_per_gpu": rows, "sharding": "one batch per GPU, no collective",
             },
             "records_per_s": round(total_rows * k / elapsed, 1),
-            "roofline": {
-                "bound": "hbm", "kernel": "mdc::emit_kernel (write pass)",
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": measured_traffic("mdc::emit_kernel", dbuf.n) if a.workload == "xml" else None,
-                "algorithmic_bytes_per_launch": int(alg_bytes),
-                "avg_launch_ms": round(write_ms, 4),
-            },
+            "roofline": roofline_of("mdc::emit_kernel (write pass)", dbuf.n, bytes_out, write_ms,
+                                    measured_traffic("mdc::emit_kernel", dbuf.n) if a.workload == "xml" else None),
             "kernel_ms": {"sizing_pass": round(acc["count"] / k, 4), "scan": round(acc["scan"] / k, 4),
                           "write_pass": round(write_ms, 4), "device_total": round(acc["total"] / k, 4)},
             "hbm_frac_whole_parse": round(alg_bytes / (acc["total"] / k * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -258,28 +463,20 @@ def main():
             ceiling = copy_ceiling(device, dbuf.ptr, dbuf.n)
             if ceiling:
                 out["roofline"]["measured_copy_GBps"] = ceiling  # hipMemcpy device to device, read + written
-                out["roofline"]["frac_of_measured_copy"] = round(achieved / ceiling, 4)
+                out["roofline"]["frac_of_measured_copy"] = round(out["roofline"]["achieved"] / ceiling, 4)
         if a.verify:
-            from oracle import oracle_lib
-            chk = oracle_lib.load("port")
-            cut = int(np.flatnonzero(data[: 8 << 20] == 10)[-1]) + 1
-            if a.workload == "xml":
-                exp = chk.parse_xml(np.ascontiguousarray(data[:cut]), schema.ZHOBTMIND)
-            else:
-                exp = chk.parse_csv(np.ascontiguousarray(data[:cut]), ",", 10, typed=schema.MIND_CSV_TYPED)
-            b = parser.parse_device(dbuf.ptr, dbuf.n)
-            ok = True
-            for c in range(exp.ncols):
-                off, dat = b.column(c)
-                n = exp.rows
-                ok &= bool(np.array_equal(off[: n + 1], exp.off[c]))
-                ok &= bool(np.array_equal(dat[: int(exp.off[c][n])], exp.data[c]))
-                if exp.val[c] is not None:
-                    ok &= bool(np.array_equal(b.values(c)[:n], exp.val[c]))
-            out["verified_records"] = int(exp.rows) if ok else 0
-            b.free()
-            if not ok:
-                raise SystemExit("GPU output differs from the CPU checker: refusing to report a number")
+            out["verified_records"] = verify_prefix(parser, dbuf, data, a.workload)
+        if arch is not None:
+            out["archive"] = arch
+        if e2e is not None:
+            e2e["plain_file_stream_GBps"] = arch["GBps_end_to_end"]
+            e2e["plain_file_threads"] = a.archive_threads
+            out["e2e"] = e2e
+    dbuf.free()
+    parser.close()
+    if rank == 0:
+        if a.workload == "xml" and a.delimited_gb > 0 and world == 1:
+            out["delimited"] = delimited_section(a, device)
         if a.cpu_sample_mb > 0 and world == 1:
             cb, _, _ = cpu_baseline(a.workload, data, a.cpu_sample_mb)
             out["cpu_baseline"] = cb
@@ -288,8 +485,6 @@ def main():
         elif a.cpu_sample_mb > 0:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    dbuf.free()
-    parser.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,63 @@
+"""The file-sharded archive (BASELINE configuration 4 in small): a sorted list of files dealt
+round-robin to 8 ranks, every rank's share through the file stream.  The one GPU here runs the
+eight shares one after the other; what is checked does not depend on which GPU ran a share: every
+file's row count against the generator's, one whole file per rank cell for cell against the CPU
+checker, and the shares being a partition of the list in sorted order."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from dsp_amd import archive, capi, gen, schema
+from util import assert_batches_equal
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_eight_shares_of_an_archive_on_one_gpu(tmp_path, port):
+    nfiles, world, file_bytes = 32, 8, 32 << 20
+    paths, rows_exp, nbytes = archive.make_files(str(tmp_path), range(nfiles), file_bytes, workers=1)
+    assert sorted(paths) == paths
+    seen = []
+    total_rows = 0
+    p = capi.Parser.xml(schema.ZHOBTMIND)
+    for rank in range(world):
+        mine = archive.rank_share(nfiles, rank, world)
+        assert mine == list(range(rank, nfiles, world))
+        keep = []
+        res = archive.run_share(p, [paths[i] for i in mine], threads=3, keep=keep)
+        assert not res.errors
+        assert res.rows_per_file == [rows_exp[i] for i in mine], f"rank {rank}"
+        assert [k for k, _ in keep] == list(range(len(mine)))  # batches come back in list order
+        total_rows += res.rows
+        seen += mine
+        # one whole file of the share against the CPU checker
+        k = rank % len(mine)
+        data = np.fromfile(paths[mine[k]], dtype=np.uint8)
+        assert_batches_equal(keep[k][1].to_host(), port.parse_xml(data, schema.ZHOBTMIND), f"file {mine[k]} of rank {rank}")
+        # the key column's first cell of every file: the file is the one the list names
+        for j, b in keep:
+            assert int(b.cell(0, 10)) == 1_000_000 + mine[j] * archive.ROWS_PER_FILE_STRIDE
+            b.free()
+    assert sorted(seen) == list(range(nfiles))
+    assert total_rows == sum(rows_exp)
+    p.close()
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    # the documented command, in small: no launcher around it, two ranks (sharing this box's GPU)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--bytes", str(32 << 20), "--archive-files-per-gpu", "2", "--archive-file-mb", "8", "--cpu-sample-mb", "0",
+           "--delimited-gb", "0", "--archive-dir", str(tmp_path)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["bytes_per_gpu"] > 30 << 20
+    assert out["archive"]["files"] == 4 and out["archive"]["rows_match_generator"]
+    assert out["archive"]["GBps_end_to_end"] > 0

@@ -106,3 +106,20 @@ def test_split_points_edge_cases():
     # "<endl/>\r\n" is not a terminator (readline keeps '\r')
     crlf = b"<a>1</a><endl/>\r\n" * 10
     assert shard.split_points(crlf, 2) == [(0, len(crlf))]
+
+
+def test_archive_shares_are_a_partition_in_sorted_order(tmp_path):
+    from dsp_amd import archive
+    for world in (1, 2, 4, 8):
+        shares = [archive.rank_share(19, r, world) for r in range(world)]
+        assert sorted(sum(shares, [])) == list(range(19))
+        assert all(s == sorted(s) for s in shares)
+    # file i is the same bytes whoever writes it, and the names sort in index order
+    a = archive.make_files(str(tmp_path / "a"), [3, 0], 1 << 16, workers=1)
+    b = archive.make_files(str(tmp_path / "b"), [0, 3], 1 << 16, workers=2)
+    assert a[1] == b[1][::-1]
+    assert open(a[0][0], "rb").read() == open(b[0][1], "rb").read()
+    assert archive.file_name(2) < archive.file_name(10)
+    gz = archive.make_files(str(tmp_path / "c"), [3], 1 << 16, gz=True, workers=1)
+    import gzip
+    assert gzip.decompress(open(gz[0][0], "rb").read()) == open(a[0][0], "rb").read()
