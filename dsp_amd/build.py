@@ -3,6 +3,7 @@
     libmdc_parse.so   the product: gfx950 kernels + C ABI (hipcc)
     libmdc_gen.so     synthetic data generator (gcc)
     examples/xmltodb_loop   the C++ ingest loop over include/mdc_xmltodb.hpp (g++)
+    examples/xmltodb_compat the reference's loop, call for call, over include/mdc_public_compat.h (g++)
 """
 from __future__ import annotations
 
@@ -79,8 +80,20 @@ def build_examples(force=False):
     return target
 
 
+def build_compat_example(force=False):
+    """The reference's ingest loop, call for call, over include/mdc_public_compat.h (g++)."""
+    target = os.path.join(ROOT, "examples", "xmltodb_compat")
+    src = os.path.join(ROOT, "examples", "xmltodb_compat.cpp")
+    deps = [src, os.path.join(ROOT, "include", "mdc_public_compat.h"), os.path.join(ROOT, "include", "mdc_parse.h"),
+            os.path.join(HERE, "libmdc_parse.so")]
+    if force or _newer(target, deps):
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), src, "-o", target,
+              "-L", HERE, "-lmdc_parse", "-Wl,-rpath,$ORIGIN/../dsp_amd"])
+    return target
+
+
 def build_all(force=False):
-    return [build_parse(force), build_gen(force), build_examples(force)]
+    return [build_parse(force), build_gen(force), build_examples(force), build_compat_example(force)]
 
 
 if __name__ == "__main__":

@@ -1,0 +1,283 @@
+// xmltodb_compat -- the ingest loop of the reference's tools/xmltodb.cpp (:256-268) and its
+// splitbuffer (:492-522), written with the reference's own calls and argument lists, compiled
+// against include/mdc_public_compat.h instead of public/_public.h.  It shows that the call sites
+// need no change, and the tests run it against the golden vectors.
+//
+//   xmltodb_compat xml <file> <cols> [endbz]   the loop: cifile::open, readline, splitbuffer (GPU record split)
+//   xmltodb_compat bulk <file> <cols> [endbz]  the same cells from cifile::splitall (every field on the GPU)
+//   xmltodb_compat records <cols>              splitbuffer over records given on stdin (one per line, hex)
+//   xmltodb_compat csv <sephex> <bdelspace> <nfields> <ilen,..> <typed,..>   ccmdstr over lines given on stdin (hex)
+//   xmltodb_compat scalar                      single calls given on stdin, one per line (see scalar_main)
+//
+// <cols> = namehex:datatype:collen,...   Output: one line per record, "row cellhex cellhex ..." ("-" = empty cell).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "mdc_public_compat.h"
+
+using namespace std;
+using namespace idc;
+
+// the part of ctcols (tools/_tools.h:17-45) the loop reads
+struct st_col {
+    char colname[32];
+    char datatype[32];
+    int collen;
+    int pkseq;
+};
+struct ctcols_t {
+    vector<st_col> m_vallcols;
+} tcols;
+vector<string> vcolvalue;
+
+// ---- the reference's call sites, as they stand ----------------------------------------------
+void splitbuffer(const string &xmlbuffer) {
+    string temp;
+    for (size_t i = 0; i < tcols.m_vallcols.size(); ++i) {
+        getxmlbuffer(xmlbuffer, tcols.m_vallcols[i].colname, temp, tcols.m_vallcols[i].collen);
+        if (strcmp(tcols.m_vallcols[i].datatype, "date") == 0) {
+            picknumber(temp, temp, false, false);
+        } else if (strcmp(tcols.m_vallcols[i].datatype, "number") == 0) {
+            picknumber(temp, temp, true, true);
+        }
+        vcolvalue[i] = temp.c_str();
+    }
+}
+
+static string hex(const string &s) {
+    if (s.empty()) return "-";
+    static const char *d = "0123456789abcdef";
+    string o;
+    for (unsigned char c : s) {
+        o.push_back(d[c >> 4]);
+        o.push_back(d[c & 15]);
+    }
+    return o;
+}
+static string unhex(const string &h) {
+    string o;
+    if (h == "-") return o;
+    for (size_t i = 0; i + 1 < h.size(); i += 2) o.push_back((char)strtol(h.substr(i, 2).c_str(), nullptr, 16));
+    return o;
+}
+static void print_row(long row) {
+    printf("%ld", row);
+    for (const string &v : vcolvalue) printf(" %s", hex(v).c_str());
+    printf("\n");
+}
+
+int _xmltodb(const string &fullfilename, const string &endbz_arg) {
+    long totalcount = 0;
+    cifile ifile;
+    if (ifile.open(fullfilename) == false) {
+        fprintf(stderr, "open failed: %s\n", ifile.errmsg().c_str());
+        return 5;
+    }
+    string xmlbuffer;
+    if (endbz_arg == "<endl/>") {
+        while (ifile.readline(xmlbuffer, "<endl/>")) {
+            ++totalcount;
+            splitbuffer(xmlbuffer);
+            print_row(totalcount - 1);
+        }
+    } else {
+        while (ifile.readline(xmlbuffer, endbz_arg)) {
+            ++totalcount;
+            splitbuffer(xmlbuffer);
+            print_row(totalcount - 1);
+        }
+    }
+    if (ifile.errcode() != MDC_OK) {
+        fprintf(stderr, "readline failed: %s\n", ifile.errmsg().c_str());
+        return 2;
+    }
+    printf("total %ld of %lld tail %s\n", totalcount, (long long)ifile.records(), hex(xmlbuffer).c_str());
+    return 0;
+}
+// ---------------------------------------------------------------------------------------------
+
+static bool parse_cols(const char *spec) {
+    ccmdstr list(spec, ",");
+    for (int i = 0; i < list.size(); ++i) {
+        ccmdstr f(list[i], ":");
+        if (f.size() < 3) return false;
+        st_col c;
+        memset(&c, 0, sizeof c);
+        snprintf(c.colname, sizeof c.colname, "%s", unhex(f[0]).c_str());  // (names come as hex: they may hold ':' or ',')
+        f.getvalue(1, c.datatype, 31);
+        c.collen = atoi(f[2].c_str());  // (a plain number: getvalue(int&) would drop a sign's place but keep "1.5" as 15)
+        tcols.m_vallcols.push_back(c);
+    }
+    vcolvalue.resize(tcols.m_vallcols.size());
+    // as preparesql() leaves the bind buffers (tools/xmltodb.cpp:424-441 with _ooci.cpp:568-573)
+    for (size_t i = 0; i < vcolvalue.size(); ++i) vcolvalue[i].resize(tcols.m_vallcols[i].collen > 0 ? tcols.m_vallcols[i].collen : 0);
+    return !tcols.m_vallcols.empty();
+}
+
+static int bulk_main(const string &file, const string &endbz) {
+    cifile ifile;
+    if (!ifile.open(file)) return 5;
+    vector<mdc_col> cols;
+    for (const st_col &c : tcols.m_vallcols) {
+        mdc_col m;
+        memset(&m, 0, sizeof m);
+        memcpy(m.colname, c.colname, 32);
+        memcpy(m.datatype, c.datatype, 32);
+        m.collen = c.collen;
+        cols.push_back(m);
+    }
+    vector<int> untyped(cols.size(), MDC_T_NONE);
+    mdc_batch *b = ifile.splitall(cols.data(), (int)cols.size(), endbz, untyped.data());
+    if (!b) {
+        fprintf(stderr, "splitall failed: %s\n", ifile.errmsg().c_str());
+        return 2;
+    }
+    const long rows = (long)mdc_batch_rows(b);
+    for (long r = 0; r < rows; ++r) {
+        for (size_t c = 0; c < cols.size(); ++c) {
+            const char *p = nullptr;
+            uint32_t len = 0;
+            if (mdc_batch_cell(b, r, (int)c, &p, &len) != MDC_OK) return 2;
+            vcolvalue[c].assign(p, len);
+        }
+        print_row(r);
+    }
+    mdc_batch_free(b);
+    return 0;
+}
+
+static int records_main() {
+    string line;
+    long row = 0;
+    while (getline(cin, line)) {
+        splitbuffer(unhex(line));
+        print_row(row++);
+    }
+    return 0;
+}
+
+template <class T>
+static string bits(const T &v) {
+    unsigned long long u = 0;
+    memcpy(&u, &v, sizeof v);
+    char buf[32];
+    snprintf(buf, sizeof buf, "%016llx", u);
+    return buf;
+}
+// typed getvalue / getxmlbuffer results in the layout of the batch's 8-byte value slots
+template <class GET>
+static string typed_result(int type, GET get) {
+    switch (type) {
+    case MDC_T_I32: { int v = 0; return get(v) ? bits((long long)v) : "null"; }
+    case MDC_T_U32: { unsigned int v = 0; return get(v) ? bits((unsigned long long)v) : "null"; }
+    case MDC_T_I64: { long v = 0; return get(v) ? bits(v) : "null"; }
+    case MDC_T_U64: { unsigned long v = 0; return get(v) ? bits(v) : "null"; }
+    case MDC_T_F64: { double v = 0; return get(v) ? bits(v) : "null"; }
+    case MDC_T_F32: { float v = 0; if (!get(v)) return "null"; unsigned int w; memcpy(&w, &v, 4); return bits((unsigned long long)w); }
+    case MDC_T_BOOL: { bool v = false; return get(v) ? bits((unsigned long long)(v ? 1 : 0)) : "null"; }
+    default: return "none";
+    }
+}
+
+static int csv_main(int argc, char **argv) {
+    if (argc < 7) return 2;
+    const string sep = unhex(argv[2]);
+    const bool bdel = atoi(argv[3]) != 0;
+    const int nfields = atoi(argv[4]);
+    ccmdstr il(argv[5], ","), ty(argv[6], ",");
+    string line;
+    long row = 0;
+    while (getline(cin, line)) {
+        ccmdstr cmdstr;
+        cmdstr.splittocmd(unhex(line), sep, bdel);
+        printf("%ld", row++);
+        for (int i = 0; i < nfields; ++i) {
+            const int ilen = i < il.size() ? atoi(il[i].c_str()) : 0, type = i < ty.size() ? atoi(ty[i].c_str()) : 0;
+            string v;
+            const bool found = cmdstr.getvalue(i, v, ilen);
+            // (the typed forms read the whole field, as the reference's do; a clipped field is converted by the
+            // bulk parser from the clipped text, which the tests cover separately)
+            printf(" %d %s %s", found ? 1 : 0, hex(v).c_str(),
+                   typed_result(type, [&](auto &x) { return ilen > 0 ? ccmdstr(v, "\x01\x02\x03").getvalue(0, x) : cmdstr.getvalue(i, x); }).c_str());
+        }
+        printf("\n");
+    }
+    return 0;
+}
+
+// one call per input line:
+//   pick <bsigned> <bdot> <texthex>         the three picknumber forms (must agree) -> hex
+//   trim <which 0 l,1 r,2 lr> <cc> <texthex> string and char* forms -> "hex hex"
+//   gxb <ilen> <namehex> <rechex>           getxmlbuffer(string&) -> hex or null, then the char* form's text
+//   conv <type> <taghex> <texthex>          typed getxmlbuffer on <tag>text</tag>, typed ccmdstr::getvalue on the text
+//   case <texthex>                          toupper, tolower
+static int scalar_main() {
+    string line;
+    while (getline(cin, line)) {
+        ccmdstr a(line, " ");
+        if (a.size() == 0) continue;
+        const string &op = a[0];
+        if (op == "pick" && a.size() == 4) {
+            const bool bs = a[1] == "1", bd = a[2] == "1";
+            const string src = unhex(a[3]);
+            string d1, same = src;
+            picknumber(src, d1, bs, bd);
+            picknumber(same, same, bs, bd);  // src and dest the same variable
+            vector<char> buf(src.size() + 1, 'x');
+            picknumber(src, buf.data(), bs, bd);
+            const bool agree = d1 == picknumber(src, bs, bd) && d1 == same && d1 == string(buf.data());
+            printf("%s\n", agree || d1.find('\0') != string::npos ? hex(d1).c_str() : "forms-disagree");
+        } else if (op == "trim" && a.size() == 4) {
+            const int which = atoi(a[1].c_str()), cc = (int)unhex(a[2])[0];
+            string s = unhex(a[3]);
+            vector<char> c(s.begin(), s.end());
+            c.push_back(0);
+            if (which == 0) { deletelchr(s, cc); deletelchr(c.data(), cc); }
+            else if (which == 1) { deleterchr(s, cc); deleterchr(c.data(), cc); }
+            else { deletelrchr(s, cc); deletelrchr(c.data(), cc); }
+            printf("%s %s\n", hex(s).c_str(), hex(string(c.data())).c_str());
+        } else if (op == "gxb" && a.size() == 4) {
+            const int ilen = atoi(a[1].c_str());
+            const string name = unhex(a[2]), rec = unhex(a[3]);
+            string v = "untouched";
+            const bool ok = getxmlbuffer(rec, name, v, ilen);
+            vector<char> buf(rec.size() + (size_t)ilen + 2, 'x');
+            getxmlbuffer(rec, name, buf.data(), ilen);
+            printf("%s %s %s\n", ok ? hex(v).c_str() : "null", ok || v == "untouched" ? "kept" : "clobbered", hex(string(buf.data())).c_str());
+        } else if (op == "conv" && a.size() == 4) {
+            const int type = atoi(a[1].c_str());
+            const string tag = unhex(a[2]), text = unhex(a[3]);
+            const string xml = "<" + tag + ">" + text + "</" + tag + ">";
+            const string viaxml = typed_result(type, [&](auto &x) { return getxmlbuffer(xml, tag, x); });
+            ccmdstr one(text, "\x01\x02\x03");
+            const string viacmd = typed_result(type, [&](auto &x) { return one.getvalue(0, x); });
+            printf("%s %s\n", viaxml.c_str(), viacmd.c_str());
+        } else if (op == "case" && a.size() == 2) {
+            string u = unhex(a[1]), l = u;
+            printf("%s %s\n", hex(toupper(u)).c_str(), hex(tolower(l)).c_str());
+        } else {
+            printf("bad-command\n");
+        }
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) {
+        fprintf(stderr, "usage: xmltodb_compat xml|bulk <file> <cols> [endbz] | records <cols> | csv ... | scalar\n");
+        return 2;
+    }
+    const string mode = argv[1];
+    if (mode == "scalar") return scalar_main();
+    if (mode == "csv") return csv_main(argc, argv);
+    if (mode == "records") return argc >= 3 && parse_cols(argv[2]) ? records_main() : 2;
+    if ((mode == "xml" || mode == "bulk") && argc >= 4 && parse_cols(argv[3])) {
+        const string endbz = argc >= 5 ? unhex(argv[4]) : "<endl/>";
+        return mode == "xml" ? _xmltodb(argv[2], endbz) : bulk_main(argv[2], endbz);
+    }
+    return 2;
+}
