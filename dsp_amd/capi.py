@@ -83,7 +83,7 @@ class CTiming(ctypes.Structure):
         ("tiles", ctypes.c_int),
         ("full_write", ctypes.c_int),
         ("lookup_tiles", ctypes.c_int),
-        ("reserved", ctypes.c_int),
+        ("long_records", ctypes.c_int),
     ]
 
 

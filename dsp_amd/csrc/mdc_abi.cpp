@@ -29,6 +29,7 @@ namespace mdc {
 hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t stream);
 hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream);
 hipError_t launch_template_kernel(const TileParams &P, hipStream_t stream);
+hipError_t launch_long_records(bool write, const TileParams &P, uint32_t count, hipStream_t stream);
 uint32_t scan_segments(uint32_t ntiles);
 hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt, uint64_t *report,
                              hipStream_t stream);
@@ -192,6 +193,7 @@ struct mdc_parser {
     bool tmpl_valid = false;        // inputs follow it (any template of this schema gives right results: a tile
                                     // whose records differ takes the table lookup), rebuilt when many tiles do not
     uint32_t *d_hdr = nullptr;      // per tile: cell map slot, first record start
+    void *d_long = nullptr;         // records longer than the look-behind: list (one LongRec per tile at most), then their cells' lengths
     uint32_t *d_cellmap = nullptr;  // (ncols + 1) x map_cap words
     size_t map_cap = 0, map_stride = 0;
     double rows_per_byte = 0;       // of the previous parse; sizes the cell map
@@ -575,6 +577,7 @@ extern "C" void mdc_parser_destroy(mdc_parser *p) {
         dev_free(p->dev, p->d_status);
         dev_free(p->dev, p->d_tmpl);
         dev_free(p->dev, p->d_hdr);
+        dev_free(p->dev, p->d_long);
         dev_free(p->dev, p->d_cellmap);
         if (p->h_report) (void)hipHostFree(p->h_report);
         for (int i = 0; i < 4; ++i)
@@ -602,20 +605,27 @@ static void batch_release(mdc_batch *b) {
 
 extern "C" void mdc_batch_free(mdc_batch *b) { batch_release(b); }
 
+// a tile may hand its first record to the long-record kernel: a list entry and the lengths of its cells
+static size_t long_bytes_per_tile(int ncols) { return sizeof(LongRec) + (size_t)ncols * 4; }
+
 static int ensure_workspace(mdc_parser *p, size_t ntiles) {
     if (ntiles <= p->ws_tiles && p->d_counts) return MDC_OK;
     dev_free(p->dev, p->d_counts);
     dev_free(p->dev, p->d_base);
     dev_free(p->dev, p->d_hdr);
+    dev_free(p->dev, p->d_long);
     p->d_counts = nullptr;
     p->d_base = nullptr;
     p->d_hdr = nullptr;
+    p->d_long = nullptr;
     p->ws_tiles = 0;
     size_t ncnt = (size_t)p->ncols + 1;
     void *a = nullptr, *b = nullptr, *h = nullptr;
     int rc = dev_alloc(p->dev, ntiles * 8 + 16, &h);
     if (rc) return rc;
     p->d_hdr = (uint32_t *)h;
+    rc = dev_alloc(p->dev, ntiles * long_bytes_per_tile(p->ncols), &p->d_long);
+    if (rc) return rc;
     rc = dev_alloc(p->dev, ntiles * ncnt * 4, &a);
     if (rc) return rc;
     rc = dev_alloc(p->dev, (ntiles + 1 + scan_segments((uint32_t)ntiles)) * ncnt * 8, &b);
@@ -667,8 +677,7 @@ static int ensure_cellmap(mdc_parser *p, size_t n, size_t ntiles) {
 
 static int status_to_error(uint32_t st) {
     if (st & ST_RECORD_TOO_LONG)
-        return fail(MDC_ERR_RECORD_TOO_LONG, "a record starts more than %d bytes in front of the tile that ends it",
-                    LBMAX);
+        return fail(MDC_ERR_RECORD_TOO_LONG, "a record of 2 GiB or more (the reference's own positions are ints)");
     if (st) return fail(MDC_ERR_INTERNAL, "kernel status %#x", st);
     return MDC_OK;
 }
@@ -688,6 +697,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
     const size_t ntiles = (n + TILE - 1) / TILE;
     uint32_t *d_counts, *d_hdr, *d_cellmap = nullptr;
     uint64_t *d_base;
+    uint8_t *d_long;
     void *d_ptrs_ext = nullptr;
     size_t map_cap = 0, map_stride = 0;
     int rc;
@@ -702,7 +712,9 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         const size_t o_base = o;
         o += ((nt + 1 + scan_segments((uint32_t)nt)) * ncnt * 8 + 255) & ~(size_t)255;
         const size_t o_counts = o;
-        o += nt * ncnt * 4;
+        o += (nt * ncnt * 4 + 255) & ~(size_t)255;
+        const size_t o_long = o;
+        o += nt * long_bytes_per_tile(p->ncols);
         if (o > NOALLOC_SCRATCH_BYTES)
             return fail(MDC_ERR_TOO_LARGE,
                         "an input of %zu bytes with %u columns needs %zu bytes of scratch; the static array holds %zu "
@@ -714,6 +726,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         d_ptrs_ext = sc + o_ptrs;
         d_base = (uint64_t *)(sc + o_base);
         d_counts = (uint32_t *)(sc + o_counts);
+        d_long = sc + o_long;
     } else {
         rc = ensure_workspace(p, ntiles ? ntiles : 1);
         if (rc) return rc;
@@ -722,6 +735,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         d_counts = p->d_counts;
         d_base = p->d_base;
         d_hdr = p->d_hdr;
+        d_long = (uint8_t *)p->d_long;
         d_cellmap = p->d_cellmap;
         map_cap = p->map_cap;
         map_stride = p->map_stride;
@@ -743,6 +757,8 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
     P.map_cap = (uint32_t)map_cap;
     P.map_stride = (uint32_t)map_stride;
     P.tile_hdr = d_hdr;
+    P.long_list = (LongRec *)d_long;
+    P.long_len = (uint32_t *)(d_long + (ntiles ? ntiles : 1) * sizeof(LongRec));
     P.tmpl = p->d_tmpl;
     P.use_tmpl = p->mode == MODE_XML ? 1u : 0u;
     P.tmpl_sample = p->tmpl_sample;
@@ -756,12 +772,14 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
 #endif
 
     hipStream_t s = d->stream;
-    // Sizing pass.  The look-behind capacity starts at the level that fitted the previous
-    // parse; a record that does not fit raises ST_RECORD_TOO_LONG and the pass is repeated
-    // with the next larger capacity (which costs blocks per CU, so it is not the default).
+    // Sizing pass.  The look-behind capacity starts at the level that fitted the previous parse.  A
+    // record that starts in front of it goes to the long-record kernel; when more than one tile in
+    // 64 met such a record, the pass is repeated with the next larger capacity (which costs blocks
+    // per CU, so it is not the default) and far fewer records take that slower way.
+    uint32_t nlong = 0;
     for (;;) {
         P.L = p->LSs[p->lb_level];
-        HIP_TRY(hipMemsetAsync(p->d_status, 0, 8, s));  // status word, tiles that left the template
+        HIP_TRY(hipMemsetAsync(p->d_status, 0, 16, s));  // status word, tiles that left the template, long records
         HIP_TRY(hipEventRecord(p->ev[0], s));
         const bool build_tmpl = P.use_tmpl && !p->tmpl_valid && ntiles;
         if (build_tmpl) HIP_TRY(launch_template_kernel(P, s));
@@ -793,9 +811,18 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
             }
             p->timing.lookup_tiles = (int)left;
         }
-        if (((uint32_t)p->h_report[0] & ST_RECORD_TOO_LONG) && p->lb_level < 2) {
+        nlong = (uint32_t)p->h_report[1];
+        if ((size_t)nlong * 64 > ntiles && p->lb_level < 2) {
             ++p->lb_level;
             continue;
+        }
+        if (nlong) {
+            // their cells' lengths enter the tiles' counters; then the prefixes and totals again
+            HIP_TRY(launch_long_records(false, P, nlong, s));
+            HIP_TRY(launch_scan_tiles(d_counts, d_base, (uint32_t)ntiles, ncnt, (uint64_t *)p->d_status + REPORT_TOTALS, s));
+            HIP_TRY(hipEventRecord(p->ev[2], s));
+            HIP_TRY(hipMemcpyAsync(p->h_report, p->d_status, (REPORT_TOTALS + ncnt) * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
         }
         break;
     }
@@ -927,6 +954,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         P.only_unmapped = 1;
         le = launch_tile_kernel(true, P, s);
     }
+    if (le == hipSuccess && nlong) le = launch_long_records(true, P, nlong, s);
     if (le != hipSuccess) {
         batch_release(b);
         return fail(MDC_ERR_HIP, "launch: %s", hipGetErrorString(le));
@@ -958,6 +986,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
     t.rows = (int64_t)rows;
     t.tiles = (int)ntiles;
     t.full_write = unmapped ? 1 : 0;
+    t.long_records = (int)nlong;
     if (out) *out = b;
     if (rows_out) *rows_out = (int64_t)rows;
     if (col_bytes)
@@ -1772,7 +1801,7 @@ extern "C" const char *mdc_strerror(int code) {
     case MDC_ERR_NO_DEVICE: return "no HIP device (no CPU fallback exists)";
     case MDC_ERR_HIP: return "HIP runtime error";
     case MDC_ERR_NOMEM: return "out of device memory";
-    case MDC_ERR_RECORD_TOO_LONG: return "record longer than the look-behind window";
+    case MDC_ERR_RECORD_TOO_LONG: return "record of 2 GiB or more";
     case MDC_ERR_TOO_LARGE: return "column larger than 4 GiB";
     case MDC_ERR_NUMERIC: return "numeric text beyond the exact-conversion range";
     case MDC_ERR_IO: return "I/O error";

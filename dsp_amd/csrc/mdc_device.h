@@ -132,6 +132,15 @@ struct LdsLayout {
     uint32_t lbmax;      // look-behind capacity in bytes (multiple of 16)
 };
 
+// A record longer than the look-behind of the tile that ends it (see long_record_kernel).
+struct LongRec {
+    uint64_t gend;  // position of the record's terminating '\n'
+    uint64_t from;  // no record terminator lies in [from, gend)
+    uint32_t tile;  // the tile that owns the record (it is that tile's first)
+    uint32_t pad;
+};
+constexpr uint32_t HDR_LONGREC = 0xFFFFFFFEu;  // tile header word 0: not mapped, and the first record is a long one
+
 struct TileParams {
     const uint8_t *data;
     uint64_t n;
@@ -158,7 +167,10 @@ struct TileParams {
     uint32_t *cellmap;
     uint32_t map_cap;            // record slots of the map = ntiles * map_stride
     uint32_t map_stride;         // record slots per tile: tile t owns [t * map_stride, (t + 1) * map_stride)
-    uint32_t *tile_hdr;          // [ntiles][2]: slot (NONE = not mapped), first record start | has_nul << 31
+    uint32_t *tile_hdr;          // [ntiles][2]: slot (NONE = not mapped), first record start | has_nul << 31;
+                                 // HDR_LONGREC, entry in long_list: not mapped and the first record is a long one
+    LongRec *long_list;          // [ntiles] long records met by the sizing pass (their number: status word 2)
+    uint32_t *long_len;          // [ntiles][ncols] bytes of each long record's cells
     uint32_t only_unmapped;      // write kernel: leave the mapped tiles to the emit kernel
     uint32_t *tmpl;              // tag template (always a valid pointer; word 0 == 0: none)
     uint32_t use_tmpl;           // tagged input: the sizing pass may use the template

@@ -178,6 +178,8 @@ enum {
     MS_WTOT = 4,    // 4 words: per-wave totals of the rank/event scan
     MS_NOMAP = 9,   // sizing pass: a cell does not fit a map word
     MS_IRR = 10,    // sizing pass: a record of the tile does not follow the tag template
+    MS_T0 = 11,     // long first record: LDS index of the first terminator of the tile
+    MS_LONGE = 12,  // long first record: its entry in the list of long records
     MS_COUNT = 16
 };
 
@@ -1277,7 +1279,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: scalar loads for per-column data)
     STAMP_INIT;
 
-    if (WRITE && P.only_unmapped && P.tile_hdr[2 * blockIdx.x] != NONE) return;  // the emit kernel has it
+    if (WRITE && P.only_unmapped && P.tile_hdr[2 * blockIdx.x] < HDR_LONGREC) return;  // the emit kernel has it
     const int64_t n = (int64_t)P.n;
     const int64_t tile_start = (int64_t)blockIdx.x * TILE;
     const int64_t tile_end = (tile_start + TILE < n) ? tile_start + TILE : n;
@@ -1424,7 +1426,9 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     }
     if (tile_start > 0) search_terminators(loaded_lo, ts_li);
     uint32_t rank_base, ev_base, nrec, nev_tile;
-    {
+    // ranks every byte by record and numbers the events: packed block-wide prefix sum of this lane's
+    // terminators and event candidates
+    auto rank_scan = [&]() {
         const uint32_t mine = ((uint32_t)__builtin_popcountll(tm) << 16) | (uint32_t)__builtin_popcountll(em);
         const uint32_t incl = wave_incl_scan(mine);
         if (lane == 63) ms[MS_WTOT + wave] = incl;
@@ -1440,10 +1444,14 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         ev_base = base & 0xFFFFu;
         nrec = tot >> 16;
         nev_tile = tot & 0xFFFFu;
-    }
-    // start of the first owned record: behind the last terminator in front of the tile
+    };
+    rank_scan();
+    const uint32_t nrec_all = nrec;  // records the tile owns (one more than it goes through when the first is a long one)
+    // start of the first owned record: behind the last terminator in front of the tile (a tile
+    // that ends no record owns none and has nothing to look for)
     int s0_li = ts_li;
-    if (tile_start > 0) {
+    bool longrec = false;  // (block-uniform) the first record starts in front of the look-behind capacity
+    if (tile_start > 0 && nrec > 0) {
         for (;;) {
             const int last = (int)ms[MS_LAST];
             if (last >= 0) {
@@ -1454,9 +1462,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 s0_li = loaded_lo;
                 break;
             }
-            if (loaded_lo == 0) {  // the record starts in front of the look-behind capacity
-                if (tid == 0) atomicOr(P.status, ST_RECORD_TOO_LONG);
-                s0_li = 0;
+            if (loaded_lo == 0) {
+                longrec = true;
                 break;
             }
             // rare: extend the staged region backwards and search it
@@ -1467,6 +1474,40 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             search_terminators(loaded_lo, hi_li);
             __syncthreads();
         }
+    }
+    uint32_t long_entry = NONE;
+    if (longrec) {
+        // The record that ends at the tile's first terminator is longer than the look-behind holds.
+        // It is left to long_record_kernel (one block per such record, straight from global memory);
+        // this tile goes on as if it began behind that terminator, with one record less.
+        if (rank_base == 0 && tm) ms[MS_T0] = (uint32_t)(my_li + __builtin_ctzll(tm));  // (one lane: the first with a terminator)
+        __syncthreads();
+        const int t0 = (int)ms[MS_T0];
+        if (!WRITE) {
+            if (tid == 0) {
+                const uint32_t e = atomicAdd(P.status + 2, 1u);
+                LongRec R;
+                R.gend = (uint64_t)(base_pos + t0);
+                R.from = (uint64_t)base_pos;  // (no terminator between here and the tile)
+                R.tile = blockIdx.x;
+                R.pad = 0;
+                P.long_list[e] = R;
+                ms[MS_LONGE] = e;
+            }
+        } else if (tid == 0) {
+            ms[MS_LONGE] = P.tile_hdr[2 * blockIdx.x + 1];
+        }
+        if (my_li + 63 < t0) {  // (a lane whose bytes all lie in front of that terminator)
+            em = 0;
+        } else if (my_li <= t0) {
+            const int b = t0 - my_li;
+            tm &= ~(1ull << b);
+            em = b == 63 ? 0 : em & (~0ull << (b + 1));
+        }
+        __syncthreads();  // (the wave totals of the first scan have been read; MS_LONGE is written)
+        long_entry = ms[MS_LONGE];
+        rank_scan();
+        s0_li = t0 + 1;
     }
     // NUL bytes of the first record's part in the look-behind count as well (a chunk that begins in
     // front of the record may add the record before: the flag only has to be set when a NUL is there)
@@ -1482,15 +1523,15 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     }
     const bool has_nul = ms[MS_HASNUL] != 0;
     // the tile's place in the cell map: map_stride record slots per tile, no allocation needed
-    const uint32_t map_slot = (!WRITE && P.cellmap && nrec <= P.map_stride) ? blockIdx.x * P.map_stride : NONE;
+    const uint32_t map_slot = (!WRITE && P.cellmap && nrec <= P.map_stride && !longrec) ? blockIdx.x * P.map_stride : NONE;
     const uint32_t RB = L.RB, EVCAP = L.evcap;
     const uint64_t *tb = WRITE ? P.tile_base + (uint64_t)blockIdx.x * (ncols + 1) : nullptr;
-    const uint64_t row0 = WRITE ? tb[ncols] : 0;
+    const uint64_t row0 = WRITE ? tb[ncols] + (longrec ? 1 : 0) : 0;  // (a long first record has the tile's first row)
     ColOut *colout = (ColOut *)(smem + L.colout);
     if (WRITE) {
         // what the sizing pass counted for this tile: the rows must agree before anything is stored
         const uint32_t *tc = P.tile_counts + (uint64_t)blockIdx.x * (ncols + 1);
-        if (tc[ncols] != nrec) {
+        if (tc[ncols] != nrec_all) {
             if (tid == 0) atomicOr(P.status, ST_INTERNAL);
             return;
         }
@@ -1502,6 +1543,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             o.base = tb[c];
             colout[c] = o;
             coltot[c] = tc[c];
+            if (longrec) tiletot[c] = P.long_len[(uint64_t)long_entry * ncols + c];  // bytes the long record's cells take
         }
     }
     if (WRITE && blockIdx.x == 0) {
@@ -2004,13 +2046,13 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         uint32_t *tc = P.tile_counts + (uint64_t)blockIdx.x * (ncols + 1);
         for (uint32_t c = tid; c < ncols; c += BLOCK) tc[c] = tiletot[c];
         if (tid == 0) {
-            tc[ncols] = nrec;
+            tc[ncols] = nrec_all;
             if (P.tile_hdr) {
                 // all batches are done (the loop ends with a barrier): is the tile's map complete?
                 const uint32_t slot = map_slot;
                 const bool mapped = slot != NONE && !ms[MS_NOMAP];
-                P.tile_hdr[2 * blockIdx.x] = mapped ? slot : NONE;
-                P.tile_hdr[2 * blockIdx.x + 1] = (uint32_t)s0_li | (has_nul ? 0x80000000u : 0u);
+                P.tile_hdr[2 * blockIdx.x] = mapped ? slot : longrec ? HDR_LONGREC : NONE;
+                P.tile_hdr[2 * blockIdx.x + 1] = longrec ? long_entry : (uint32_t)s0_li | (has_nul ? 0x80000000u : 0u);
                 if (!mapped) atomicOr(P.status, ST_UNMAPPED);
             }
         }
@@ -2139,7 +2181,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     const uint64_t row0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(row0_v >> 32)) << 32) |
                           __builtin_amdgcn_readfirstlane((uint32_t)row0_v);
 
-    if (hslot == NONE || nrec == 0) return;  // no map (the full write kernel has the tile), or nothing to write
+    if (hslot >= HDR_LONGREC || nrec == 0) return;  // no map (the full write kernel has the tile), or nothing to write
     const int s0_li = (int)(hw & 0x7FFFFFFFu);
     const bool has_nul = (hw >> 31) != 0;
 #pragma unroll
@@ -2231,6 +2273,326 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     bool differ = overrun;
     for (uint32_t c = tid; c < ncols; c += BLOCK) differ |= tiletot[c] != sized[c];
     if (differ) atomicOr(P.status, ST_INTERNAL);
+}
+
+// ---------------------------------------------------------------------------------------
+// Records longer than the look-behind capacity of the tile that ends them.  cifile::readline
+// (reference public/_public.cpp:866-892) puts no bound on a record, so neither does the parser:
+// the sizing pass lists such records (they are always the first record of their tile) and this
+// kernel does what the tile kernel does for a record, with one block per record and every byte
+// read straight from global memory: record start, getxmlbuffer's two first-occurrence searches per
+// column (or splittocmd's greedy separator search), clip, carry-forward, filter, NUL cut.
+// WRITE = false adds the cells' lengths to the owning tile's counters (and keeps them for the
+// write pass); WRITE = true stores the record's row.  Typed values are left to the second stage
+// (deferred_convert_kernel), as for every cell of more than 16 source bytes.  Speed does not
+// matter here; a record of 2 GiB or more is refused (the reference's own positions are ints).
+__device__ __forceinline__ uint32_t gbyte(const uint8_t *data, int64_t n, int64_t pos) {
+    return pos >= 0 && pos < n ? data[pos] : 0u;
+}
+__device__ __forceinline__ uint4 gchunk(const uint8_t *data, int64_t n, int64_t pos) {  // pos is a multiple of 16
+    if (pos >= 0 && pos + 16 <= n) return *(const uint4 *)(data + pos);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 16; ++k) w[k >> 2] |= gbyte(data, n, pos + k) << (8 * (k & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ bool gterm(const uint8_t *data, const SchemaHdr *H, int64_t p) {  // is the '\n' at p a terminator?
+    const int el = (int)H->endbz_len;
+    if (p - el < 0) return el == 0;
+    for (int k = 0; k < el; ++k)
+        if (data[p - el + k] != H->endbz[k]) return false;
+    return true;
+}
+// does byte k of a cell pass the filter of its level?
+__device__ __forceinline__ bool level_pass(uint32_t b, uint32_t lvl) {
+    const bool dig = (b - '0') < 10u;
+    return lvl == LVL_CHAR ? true : lvl == LVL_NUMBER ? (dig | (b == '+') | (b == '-') | (b == '.')) : dig;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ uint32_t sh[8];
+    __shared__ uint32_t wsum[BLOCK / 64];
+    __shared__ uint16_t cand[BLOCK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const LongRec R = P.long_list[blockIdx.x];
+    const uint8_t *data = P.data;
+    const int64_t n = (int64_t)P.n;
+    for (uint32_t i = tid; i < P.schema_bytes / 16; i += BLOCK) ((uint4 *)smem)[i] = ((const uint4 *)P.schema)[i];
+    if (tid < 8) sh[tid] = 0;
+    __syncthreads();
+    const SchemaHdr *H = (const SchemaHdr *)smem;
+    const DevCol *cols = (const DevCol *)(H + 1);
+    const uint32_t ncols = H->ncols, W = H->words;
+    const HtEntry *ht = (const HtEntry *)((const uint8_t *)cols + ((ncols * sizeof(DevCol) + 15) & ~15u));
+    const bool csv = H->mode == MODE_CSV;
+    const bool nulcut = H->carry != 0 && !csv;
+    uint32_t *work = (uint32_t *)(smem + ((P.schema_bytes + 15) & ~15u));
+    uint32_t *first = work;                 // XML: first position of every pattern; delimited: the separators
+    uint32_t *dstart = work + 2 * ncols;    // the cells' sources ...
+    uint32_t *dlen = dstart + ncols;
+    uint32_t *dlvl = dlen + ncols;          // ... level | found << 8
+    const int64_t gend = (int64_t)R.gend;
+
+    // 1. the record's start: behind the last terminator in front of `from` (multiples of 16 down to 0)
+    int64_t gstart = 0;
+    for (int64_t hi = (int64_t)R.from; hi > 0;) {
+        const int64_t lo = hi - BLOCK * CHUNK > 0 ? hi - BLOCK * CHUNK : 0;
+        const int64_t pos = lo + (int64_t)tid * CHUNK;
+        if (pos < hi) {
+            uint32_t nl = mask16_eq(gchunk(data, n, pos), 0x0A0A0A0Au);
+            while (nl) {
+                const int b = 31 - __builtin_clz(nl);  // the last one first
+                nl &= ~(1u << b);
+                if (gterm(data, H, pos + b)) {
+                    atomicMax(&sh[0], (uint32_t)(pos + b - lo) + 1);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t hit = sh[0];
+        __syncthreads();
+        if (hit) {
+            gstart = lo + hit;  // (hit - 1 is the terminator's place in the window)
+            break;
+        }
+        hi = lo;
+    }
+    if (gend - gstart >= ((int64_t)1 << 31)) {
+        if (tid == 0) atomicOr(P.status, ST_RECORD_TOO_LONG);
+        return;
+    }
+    const uint32_t reclen = (uint32_t)(gend - gstart);  // the record's text: the '\n' is not part of it
+
+    // 2. where the fields are
+    const uint32_t seplen = H->sep_len;
+    for (uint32_t i = tid; i < 2 * ncols; i += BLOCK) first[i] = NONE;
+    __syncthreads();
+    if (!csv) {
+        for (int64_t cb = gstart & ~(int64_t)15; cb < gend; cb += BLOCK * CHUNK) {
+            const int64_t pos = cb + (int64_t)tid * CHUNK;
+            if (pos >= gend) continue;
+            uint32_t m = mask16_eq(gchunk(data, n, pos), 0x3C3C3C3Cu);
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1;
+                const int64_t q = pos + b;
+                if (q < gstart || q >= gend) continue;
+                // the key: up to eight bytes behind '<', through the first '>' (as tag_key)
+                uint32_t kw[2] = {0, 0};
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t c = gbyte(data, n, q + 1 + k);
+                    kw[k >> 2] |= c << (8 * (k & 3));
+                    if (c == '>') break;
+                }
+                TagKey key;
+                key.lo = kw[0];
+                key.hi = kw[1];
+                uint32_t slot = tag_slot(H, key);
+                if (!(ht[slot].meta >> 31)) continue;
+                for (;;) {
+                    const HtEntry &e = ht[slot];
+                    const uint32_t tlen = e.meta & 0xFFu, kind = (e.meta >> 8) & 1u, col = (e.meta >> 16) & 0x3FFFu;
+                    bool ok = e.klo == key.lo && e.khi == key.hi;
+                    if (ok && tlen >= 8) {  // the key covers eight bytes of the text; the rest, then '>'
+                        for (uint32_t k = 8; ok && k < tlen; ++k) ok = gbyte(data, n, q + 1 + k) == cols[col].name[k - kind];
+                        ok = ok && gbyte(data, n, q + 1 + tlen) == '>';
+                    }
+                    if (ok) atomicMin(&first[2 * col + kind], (uint32_t)(q - gstart));
+                    slot = e.next;
+                    if (!slot) break;
+                }
+            }
+        }
+    } else {
+        // the first ncols separators, left to right without overlap (ccmdstr::splittocmd): all lanes
+        // mark where the separator's text stands, one lane walks the marks in order
+        uint32_t nsep = 0, allowed = 0;  // (thread 0's) separators found, first position a match may start at
+        for (int64_t cb = gstart & ~(int64_t)15; cb < gend; cb += BLOCK * CHUNK) {
+            const int64_t pos = cb + (int64_t)tid * CHUNK;
+            uint32_t m = 0;
+            if (pos < gend) {
+                m = mask16_eq(gchunk(data, n, pos), rep4(H->sep[0]));
+                uint32_t keep = 0;
+                while (m) {
+                    const int b = __builtin_ctz(m);
+                    m &= m - 1;
+                    const int64_t q = pos + b;
+                    bool ok = q >= gstart && q + seplen <= gend;
+                    for (uint32_t k = 1; ok && k < seplen; ++k) ok = data[q + k] == H->sep[k];
+                    if (ok) keep |= 1u << b;
+                }
+                m = keep;
+            }
+            cand[tid] = (uint16_t)m;
+            __syncthreads();
+            if (tid == 0) {
+                for (int t = 0; t < BLOCK && nsep < ncols; ++t) {
+                    uint32_t x = cand[t];
+                    while (x && nsep < ncols) {
+                        const int b = __builtin_ctz(x);
+                        x &= x - 1;
+                        const uint32_t rel = (uint32_t)(cb + t * CHUNK + b - gstart);
+                        if (rel >= allowed) {
+                            first[nsep++] = rel;
+                            allowed = rel + seplen;
+                        }
+                    }
+                }
+                sh[1] = nsep;
+            }
+            __syncthreads();
+            if (sh[1] >= ncols) break;
+        }
+    }
+    __syncthreads();
+
+    // 3. the cells' sources (as fetch_cell of the tile kernel, with positions relative to the record)
+    for (uint32_t c = tid; c < ncols; c += BLOCK) {
+        uint32_t s = 0, len = 0, lvl = LVL_CHAR;
+        bool found = false;
+        if (csv) {
+            const uint32_t nsep = sh[1];
+            if (c <= nsep) {
+                found = true;
+                s = c ? first[c - 1] + seplen : 0;
+                len = (c < nsep ? first[c] : reclen) - s;
+                if (H->bdelspace) {  // deletelchr, then deleterchr with its "pos != 0" test (public/_public.cpp:24-31, :52-59)
+                    while (len && data[gstart + s] == ' ') {
+                        ++s;
+                        --len;
+                    }
+                    if (len) {
+                        uint32_t lastp = len - 1;
+                        while (data[gstart + s + lastp] == ' ') --lastp;
+                        if (lastp != 0) len = lastp + 1;
+                    }
+                }
+                const int cl = cols[c].collen;
+                if (cl > 0 && (uint32_t)cl < len) len = (uint32_t)cl;
+            }
+        } else {
+            uint32_t o = first[2 * c], e = first[2 * c + 1];
+            found = (o != NONE) & (e != NONE);
+            uint32_t cs = c;
+            lvl = cols[c].level;
+            bool have = found;
+            if (!found && H->carry)
+                while (cs > 0) {
+                    --cs;
+                    o = first[2 * cs];
+                    e = first[2 * cs + 1];
+                    if (cols[cs].level > lvl) lvl = cols[cs].level;
+                    if ((o != NONE) & (e != NONE)) {
+                        have = true;
+                        break;
+                    }
+                }
+            if (have) {
+                s = o + cols[cs].namelen + 2;
+                const int cl = cols[cs].collen;
+                int64_t l = (int64_t)e - (int64_t)s;
+                if (l < 0)
+                    l = (int64_t)reclen - (int64_t)s;  // close tag in front of the open tag: rest of the record
+                else if (cl > 0 && cl < l)
+                    l = cl;
+                len = (uint32_t)l;
+            }
+        }
+        dstart[c] = s;
+        dlen[c] = len;
+        dlvl[c] = lvl | ((uint32_t)found << 8);
+    }
+    __syncthreads();
+
+    // 4. column by column: NUL cut, filtered length, and the bytes
+    const uint64_t *tb = WRITE ? P.tile_base + (uint64_t)R.tile * (ncols + 1) : nullptr;
+    const uint64_t row = WRITE ? tb[ncols] : 0;
+    bool deferred = false;
+    for (uint32_t c = 0; c < ncols; ++c) {
+        const int64_t src = gstart + dstart[c];
+        uint32_t len = dlen[c];
+        const uint32_t lvl = dlvl[c] & 3u;
+        const bool found = (dlvl[c] >> 8) & 1u;
+        if (lvl == LVL_CHAR && nulcut) {  // vcolvalue[i] = temp.c_str(): the text ends at its first NUL
+            if (tid == 0) sh[2] = len;
+            __syncthreads();
+            uint32_t cut = len;
+            for (uint32_t k0 = 0; k0 < len && cut == len; k0 += BLOCK * CHUNK) {
+                for (uint32_t k = k0 + tid * CHUNK; k < k0 + (tid + 1) * CHUNK && k < len; ++k)
+                    if (data[src + k] == 0) {
+                        atomicMin(&sh[2], k);
+                        break;
+                    }
+                __syncthreads();
+                cut = sh[2];
+                __syncthreads();  // (everyone has read the word before the next window may lower it)
+            }
+            len = cut;
+        }
+        // the filtered length, and with WRITE the surviving bytes in order
+        uint8_t *dst = WRITE ? P.bytes[c] + tb[c] : nullptr;
+        uint32_t flen = 0;  // (block-uniform running total)
+        for (uint32_t k0 = 0; k0 < len; k0 += BLOCK * CHUNK) {
+            const uint32_t kb = k0 + tid * CHUNK;
+            uint32_t cnt = 0;
+            uint8_t keep[CHUNK];
+            for (uint32_t k = 0; k < CHUNK; ++k)
+                if (kb + k < len) {
+                    const uint32_t b = data[src + kb + k];
+                    if (level_pass(b, lvl)) keep[cnt++] = (uint8_t)b;
+                }
+            const uint32_t incl = wave_incl_scan(cnt);
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t before = incl - cnt, tot = 0;
+            for (int w = 0; w < BLOCK / 64; ++w) {
+                if (w < wave) before += wsum[w];
+                tot += wsum[w];
+            }
+            if (WRITE)
+                for (uint32_t k = 0; k < cnt; ++k) dst[flen + before + k] = keep[k];
+            flen += tot;
+            __syncthreads();
+        }
+        const uint32_t typed = cols[c].typed;
+        if (typed != T_NONE && (found || nulcut)) deferred = true;
+        if (tid == 0) {
+            if (!WRITE) {
+                P.long_len[(uint64_t)blockIdx.x * ncols + c] = flen;
+                P.tile_counts[(uint64_t)R.tile * (ncols + 1) + c] += flen;  // (this record is no other block's)
+            } else {
+                P.off[c][row + 1] = (uint32_t)(tb[c] + flen);
+                if (typed != T_NONE) P.val[c][row] = 0;
+            }
+        }
+    }
+    if (WRITE) {
+        if ((uint32_t)tid < W) {
+            uint32_t fm = 0;
+            for (uint32_t c = tid * 32; c < ncols && c < (uint32_t)tid * 32 + 32; ++c) fm |= ((dlvl[c] >> 8) & 1u) << (c & 31);
+            P.found[row * W + tid] = fm;
+            P.valid[row * W + tid] = 0;
+        }
+        if (tid == 0 && P.rec_off) P.rec_off[row + 1] = (uint64_t)gend + 1;
+        if (deferred && tid == 0) atomicOr(P.status, ST_NUMERIC_RANGE);
+    }
+}
+
+hipError_t launch_long_records(bool write, const TileParams &P, uint32_t count, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    const uint32_t lds = ((P.schema_bytes + 15) & ~15u) + 5 * P.ncols * 4 + 64;
+    if (lds > 48 * 1024) {  // (beside the kernel's few static words)
+        const void *fn = write ? (const void *)long_record_kernel<true> : (const void *)long_record_kernel<false>;
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (write)
+        hipLaunchKernelGGL(long_record_kernel<true>, dim3(count), dim3(BLOCK), lds, stream, P);
+    else
+        hipLaunchKernelGGL(long_record_kernel<false>, dim3(count), dim3(BLOCK), lds, stream, P);
+    return hipGetLastError();
 }
 
 // Exclusive prefix over tiles of every counter, in two small kernels.  (1) One block per

@@ -70,7 +70,7 @@ enum {
     MDC_ERR_NO_DEVICE = -2,     /* no usable HIP device: there is no CPU fallback             */
     MDC_ERR_HIP = -3,           /* a HIP runtime call failed                                  */
     MDC_ERR_NOMEM = -4,
-    MDC_ERR_RECORD_TOO_LONG = -5, /* a record longer than the parser's look-behind window   */
+    MDC_ERR_RECORD_TOO_LONG = -5, /* a record of 2 GiB or more (the reference's positions are ints) */
     MDC_ERR_TOO_LARGE = -6,     /* a column's cells exceed 4 GiB in one batch: split input    */
     MDC_ERR_NUMERIC = -7,       /* numeric text beyond the exact-conversion range            */
     MDC_ERR_IO = -8,
@@ -111,7 +111,7 @@ typedef struct mdc_timing {
     int full_write;  /* 1 = some tiles had no cell map and went through the full write kernel */
     int lookup_tiles; /* tagged input: tiles whose records did not all repeat the sampled record's tags */
                       /* and took the tag table instead (0 for delimited input)                         */
-    int reserved;
+    int long_records; /* records longer than the look-behind window, parsed by the long-record kernel */
 } mdc_timing;
 
 /* ---- library ------------------------------------------------------------------------ */
@@ -156,8 +156,8 @@ int mdc_parse_file(mdc_parser *p, const char *path, mdc_batch **out);
  * library's own workspace (per-tile counters, their prefixes, tile headers, the table of output
  * pointers) lies in a static device array of MDC_NOALLOC_SCRATCH_BYTES that every GPU the
  * library runs on holds until the process ends.
- *   limit    tiles x (columns + 1) x 12 bytes and some headers must fit the array: about
- *            215 MiB of input with 11 columns, 20 MiB with 128; beyond that MDC_ERR_TOO_LARGE
+ *   limit    per 16 KiB of input, 16 x columns + 52 bytes must fit the array: about 140 MiB of
+ *            input with 11 columns, 15 MiB with 128; beyond that MDC_ERR_TOO_LARGE
  *            (use mdc_parse_device, or parse the input in parts)
  *   outputs  per column: rows_cap + 1 u32 offsets, bytes_cap bytes of cells, and for a typed
  *            column rows_cap u64 values; rows_cap x mdc_batch_words_per_row words each of valid

@@ -124,11 +124,115 @@ def test_records_straddling_tiles(port, reclen):
     assert_batches_equal(got, exp, f"straddle {reclen}")
 
 
-def test_record_too_long_is_an_error():
-    data = b"<a>1</a>" + b"x" * 40000 + b"<endl/>\n"
-    with pytest.raises(capi.MdcError) as e:
-        gpu_xml(data, cases.SMALL)
-    assert e.value.code == capi.MDC_ERR_RECORD_TOO_LONG
+def _long_xml_record(rng, i, total, variant):
+    """One record of about `total` bytes for the SMALL schema (a text, ab text, b number)."""
+    fill = bytes(rng.integers(97, 123, size=total, dtype=np.uint8))
+    if variant == 0:    # a long text cell
+        return b"<a>%d</a><ab>" % i + fill + b"</ab><b>%d.5</b><endl/>\n" % i
+    if variant == 1:    # padding between the fields, tag-like text and newlines inside
+        return b"<a>k%d</a>\n" % i + fill[:total // 2] + b"<x><a></b>\n" + fill[total // 2:] + b"<b>-%d.25</b><ab>z</ab><endl/>\n" % i
+    if variant == 2:    # close tag in front of the open tag: the cell is the rest of the record; a NUL cuts it
+        return b"</ab><ab>rest" + fill[:total // 3] + b"\0" + fill[total // 3:] + b"<a>7</a><endl/>\n"
+    if variant == 3:    # a long number: digits with other bytes between them, no <ab> (the value carries over)
+        digits = bytes(rng.integers(48, 58, size=total, dtype=np.uint8))
+        return b"<a>n%d</a><b>1" % i + digits + b"x.5</b><endl/>\n"
+    return b"<b>%d</b>" % i + fill + b"<endl/>\n"  # no <a>, no <ab>
+
+
+@pytest.mark.parametrize("total", [17000, 40000, 1 << 20])
+def test_records_longer_than_the_look_behind(port, total):
+    # cifile::readline puts no bound on a record: such records go through the long-record kernel
+    rng = np.random.default_rng(total)
+    short = [b"<a>%d</a><ab>s</ab><b>%d.5</b><endl/>\n" % (i, i) for i in range(400)]
+    parts = [b"<data>\n"]
+    nlong = 0
+    for v in range(5):
+        parts += short[80 * v:80 * v + 80 - 7 * v]
+        parts.append(_long_xml_record(rng, v, total, v))
+        nlong += 1
+    parts += [_long_xml_record(rng, 9, total, 0), _long_xml_record(rng, 10, total, 1)]  # two in a row
+    nlong += 2
+    parts += short[:50] + [b"</data>\n"]
+    data = b"".join(parts)
+    for typed in (None, [schema.T_NONE, schema.T_F64, schema.T_I64, schema.T_NONE, schema.T_I32],
+                  [schema.T_I64, schema.T_F32, schema.T_U64, schema.T_BOOL, schema.T_F64]):
+        p = capi.Parser.xml(cases.SMALL, typed=typed)
+        got = p.parse_host(data).to_host()
+        # (a record of 17,000 bytes fits the largest look-behind when its terminator lies deep enough in its tile)
+        assert p.timing().long_records == nlong if total >= 40000 else p.timing().long_records >= 1
+        exp = port.parse_xml(data, cases.SMALL, typed=typed)
+        assert_batches_equal(got, exp, f"long records of {total} bytes, typed {typed}")
+        # the same parser, a second time (workspace reuse), and without the carry-forward
+        assert_batches_equal(p.parse_host(data).to_host(), exp, "second parse")
+        p.close()
+    got = gpu_xml(data, cases.SMALL, carry=False)
+    assert_batches_equal(got, port.parse_xml(data, cases.SMALL, carry=False), "long records, independent columns")
+
+
+def test_long_record_ending_at_every_byte_of_a_lane(port):
+    # the tile that ends a long record goes on without that record's terminator, which may be any
+    # byte of the 64 a lane owns (the last one included) and any lane of the tile (the first and last included)
+    rng = np.random.default_rng(11)
+    body = bytes(rng.integers(97, 123, size=70000, dtype=np.uint8))
+    after = b"<a>2</a><b>3.5</b><endl/>\n" * 3
+    p = capi.Parser.xml(cases.SMALL)
+    for off in list(range(60, 132)) + [0, 1, 7, 16383, 16382, 16320]:
+        n = 3 * 16384 + off  # position of the long record's terminating newline
+        rec = b"<a>1</a><ab>" + body[: n - 12 - 12] + b"</ab><endl/>"
+        assert len(rec) == n
+        data = rec + b"\n" + after
+        got = p.parse_host(data).to_host()
+        assert p.timing().long_records == 1
+        assert_batches_equal(got, port.parse_xml(data, cases.SMALL), f"terminator at tile offset {off}")
+    p.close()
+
+
+def test_a_long_first_record_and_a_long_unterminated_tail(port):
+    rng = np.random.default_rng(5)
+    first = _long_xml_record(rng, 1, 70000, 0)
+    tail = b"<a>never ends</a>" + bytes(rng.integers(97, 123, size=50000, dtype=np.uint8))
+    data = first + b"<a>2</a><endl/>\n" * 3 + tail
+    got = gpu_xml(data, cases.SMALL)
+    assert_batches_equal(got, port.parse_xml(data, cases.SMALL), "long first record, long tail without terminator")
+    assert got.rows == 4
+
+
+def test_a_file_of_records_just_longer_than_every_look_behind(port):
+    # every tile meets a record that does not fit: the parser first tries its larger look-behind
+    # capacities and then hands what is still too long to the long-record kernel
+    rng = np.random.default_rng(6)
+    for size, exact in ((16400, False), (33000, True)):
+        recs = [_long_xml_record(rng, i, size + 37 * (i % 5), i % 5) for i in range(60)]
+        data = b"".join(recs)
+        p = capi.Parser.xml(cases.SMALL)
+        got = p.parse_host(data).to_host()
+        # (a record of 16,400 bytes still fits when its terminator lies deep enough in its tile)
+        assert p.timing().long_records == 60 if exact else p.timing().long_records >= 1
+        assert_batches_equal(got, port.parse_xml(data, cases.SMALL), f"many long records of {size} bytes")
+        p.close()
+
+
+@pytest.mark.parametrize("sep,bdel", [(",", False), ("~!~", True), (" ", True)])
+def test_delimited_lines_longer_than_the_look_behind(port, sep, bdel):
+    rng = np.random.default_rng(len(sep) + bdel)
+    s = sep.encode()
+    lines = []
+    for i in range(300):
+        lines.append(s.join([b"%d" % i, b" x%d " % i, b"%d.5" % i, b"tail"]) + b"\n")
+        if i % 60 == 7:
+            big = bytes(rng.integers(97, 123, size=30000 + 1000 * i, dtype=np.uint8))
+            fields = [b"  " + big[:10000] + b"  ", b"%d" % i, b"-12.5", big[10000:], b"more", b"and more"][: 3 + i % 4]
+            lines.append(s.join(fields) + b"\n")
+        if i % 100 == 50:  # a long line without any separator, and one of separators only
+            lines.append(bytes(rng.integers(97, 123, size=20000, dtype=np.uint8)) + b"\n")
+            lines.append(s * 9000 + b"\n")
+    data = b"".join(lines)
+    typed = [schema.T_I64, schema.T_NONE, schema.T_F64, schema.T_NONE, schema.T_NONE]
+    p = capi.Parser.csv(sep, 5, ilen=[0, 0, 0, 25000, 3], typed=typed, bdelspace=bdel)
+    got = p.parse_host(data).to_host()
+    assert p.timing().long_records >= 5
+    assert_batches_equal(got, port.parse_csv(data, sep, 5, ilen=[0, 0, 0, 25000, 3], typed=typed, bdelspace=bdel), f"long lines, sep {sep!r}")
+    p.close()
 
 
 def test_long_cells_bypass_staging(port):

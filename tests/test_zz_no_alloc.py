@@ -81,7 +81,9 @@ def test_two_calls_in_a_row_equal_the_allocating_entry_point():
     big, nbig = gen.mind_xml(rows=40000)      # ~6.9 MB, 420 tiles
     small, nsmall = gen.mind_xml(rows=1700, first_row=77)
     # missing tags and a long cell in the second input: other code paths than the first
-    small = np.concatenate([small, np.frombuffer(b"<obtid>59999</obtid><t>-1.5e3</t><vis>" + b"7" * 40 + b"</vis><endl/>\n", np.uint8)])
+    # ... and a record longer than any look-behind (its list entry and cell lengths lie in the scratch array too)
+    small = np.concatenate([small, np.frombuffer(b"<obtid>59999</obtid><t>-1.5e3</t><vis>" + b"7" * 40 + b"</vis><endl/>\n" +
+                                                 b"<obtid>60000</obtid><junk>" + b"j" * 50000 + b"</junk><t>2.5</t><endl/>\n", np.uint8)])
     out = Outputs(11, typed, rows_cap=nbig + 10, bytes_cap=1 << 20)
     for data in (big, small):
         d = capi.DeviceBuffer(data)
