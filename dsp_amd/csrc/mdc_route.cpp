@@ -305,3 +305,94 @@ extern "C" int mdc_bind_plan(const mdc_xmltotable *entry, const mdc_col *cols, i
     *nupd = k;
     return MDC_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// the execute loop in bulk (tools/xmltodb.cpp:263-306)
+
+extern "C" int mdc_batch_bind_slabs(mdc_batch *b, const mdc_xmltotable *entry, const mdc_col *cols, int ncols,
+                                    mdc_bind_slab *ins, int *nins, mdc_bind_slab *upd, int *nupd) {
+    if (!b || !entry || !cols || ncols < 1 || !ins || !nins)
+        return mdc_internal_fail(MDC_ERR_ARG, "mdc_batch_bind_slabs: bad argument");
+    if (mdc_batch_ncols(b) != ncols) return mdc_internal_fail(MDC_ERR_ARG, "mdc_batch_bind_slabs: the batch has another number of columns");
+    std::vector<int> pi((size_t)ncols), pu((size_t)ncols);
+    int ni = 0, nu = 0;
+    int rc = mdc_bind_plan(entry, cols, ncols, pi.data(), &ni, pu.data(), &nu);
+    if (rc) return rc;
+    if (nu && (!upd || !nupd)) return mdc_internal_fail(MDC_ERR_ARG, "mdc_batch_bind_slabs: update slabs wanted but no room given");
+    auto fill = [&](const int *plan, int n, mdc_bind_slab *out) {
+        for (int k = 0; k < n; ++k) {
+            out[k].col = plan[k];
+            out[k].pad = 0;
+            const int r = mdc_batch_column_fixed(b, plan[k], &out[k].base, &out[k].stride);
+            if (r) return r;
+        }
+        return (int)MDC_OK;
+    };
+    if ((rc = fill(pi.data(), ni, ins))) return rc;
+    *nins = ni;
+    if (nupd) *nupd = 0;
+    if (nu) {
+        if ((rc = fill(pu.data(), nu, upd))) return rc;
+        *nupd = nu;
+    }
+    return MDC_OK;
+}
+
+// the error numbers that mean the connection is gone (tools/xmltodb.cpp:297-301)
+static bool connection_lost(int code) { return code == 3113 || code == 3114 || code == 3135 || code == 16014; }
+
+extern "C" int mdc_ingest_rows(const mdc_bind_slab *ins, int nins, const mdc_bind_slab *upd, int nupd, int64_t rows,
+                               int uptbz, mdc_array_exec exec, void *ctx, mdc_ingest_counts *counts) {
+    if (!counts || !exec || rows < 0 || nins < 0 || nupd < 0 || (nins && !ins) || (nupd && !upd))
+        return mdc_internal_fail(MDC_ERR_ARG, "mdc_ingest_rows: bad argument");
+    if (uptbz == 1 && !upd && rows) return mdc_internal_fail(MDC_ERR_ARG, "mdc_ingest_rows: uptbz is 1 but there are no update slabs");
+    memset(counts, 0, sizeof *counts);
+    counts->totalcount = rows;
+    if (rows == 0) return MDC_OK;
+    std::vector<int> code((size_t)rows, 0);
+    if (exec(ctx, 0, ins, nins, rows, code.data()) != 0) {
+        counts->result = 2;
+        return MDC_OK;
+    }
+    // the decisions of :271-303, row by row in file order
+    std::vector<int64_t> dup;
+    for (int64_t r = 0; r < rows; ++r) {
+        const int c = code[(size_t)r];
+        if (c == 0) {
+            ++counts->inscount;
+        } else if (c == 1) {
+            ++counts->duplicates;
+            if (uptbz == 1) dup.push_back(r);
+        } else {
+            ++counts->insfailed;
+            if (connection_lost(c)) {  // (the reference returns here: no row behind this one is looked at, nothing is committed)
+                counts->result = 2;
+                counts->fatalcode = c;
+                return MDC_OK;
+            }
+        }
+    }
+    if (dup.empty()) return MDC_OK;
+    // the rejected rows, in row order, in the update statement's bind order
+    std::vector<std::vector<char>> store((size_t)nupd);
+    std::vector<mdc_bind_slab> us((size_t)nupd);
+    for (int k = 0; k < nupd; ++k) {
+        const size_t st = upd[k].stride;
+        store[(size_t)k].resize(dup.size() * st);
+        for (size_t i = 0; i < dup.size(); ++i) memcpy(&store[(size_t)k][i * st], upd[k].base + (size_t)dup[i] * st, st);
+        us[(size_t)k] = upd[k];
+        us[(size_t)k].base = store[(size_t)k].data();
+    }
+    std::vector<int> ucode(dup.size(), 0);
+    if (exec(ctx, 1, us.data(), nupd, (int64_t)dup.size(), ucode.data()) != 0) {
+        counts->result = 2;
+        return MDC_OK;
+    }
+    for (const int c : ucode) {
+        if (c == 0)
+            ++counts->uptcount;
+        else
+            ++counts->uptfailed;  // (data the table does not take: logged by the reference, the file goes on, :281-286)
+    }
+    return MDC_OK;
+}

@@ -13,7 +13,24 @@ from .schema import Col, c_cols
 ROUTE_EXPORTS = [
     "mdc_route_load", "mdc_route_load_buffer", "mdc_route_free", "mdc_route_count", "mdc_route_truncated",
     "mdc_route_entry", "mdc_route_find", "mdc_matchstr", "mdc_crtsql", "mdc_bind_plan",
+    "mdc_batch_bind_slabs", "mdc_ingest_rows",
 ]
+
+
+class CBindSlab(ctypes.Structure):
+    """mdc_bind_slab: one bound column as fixed-stride NUL-terminated slots."""
+
+    _fields_ = [("base", ctypes.c_void_p), ("stride", ctypes.c_size_t), ("col", ctypes.c_int), ("pad", ctypes.c_int)]
+
+
+class CIngestCounts(ctypes.Structure):
+    _fields_ = [("totalcount", ctypes.c_int64), ("inscount", ctypes.c_int64), ("uptcount", ctypes.c_int64),
+                ("insfailed", ctypes.c_int64), ("uptfailed", ctypes.c_int64), ("duplicates", ctypes.c_int64),
+                ("result", ctypes.c_int), ("fatalcode", ctypes.c_int)]
+
+
+ARRAY_EXEC = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(CBindSlab), ctypes.c_int,
+                              ctypes.c_int64, ctypes.POINTER(ctypes.c_int))
 
 
 class CXmlToTable(ctypes.Structure):
@@ -50,6 +67,10 @@ def _lib():
                                  ctypes.c_char_p, sz, ctypes.POINTER(sz)]
         L.mdc_bind_plan.argtypes = [ctypes.POINTER(CXmlToTable), vp, ci, vp, ctypes.POINTER(ci), vp,
                                     ctypes.POINTER(ci)]
+        L.mdc_batch_bind_slabs.argtypes = [vp, ctypes.POINTER(CXmlToTable), vp, ci, ctypes.POINTER(CBindSlab),
+                                           ctypes.POINTER(ci), ctypes.POINTER(CBindSlab), ctypes.POINTER(ci)]
+        L.mdc_ingest_rows.argtypes = [ctypes.POINTER(CBindSlab), ci, ctypes.POINTER(CBindSlab), ci, ctypes.c_int64, ci,
+                                      ARRAY_EXEC, vp, ctypes.POINTER(CIngestCounts)]
         _ready = True
     return L
 
@@ -131,3 +152,47 @@ def bind_plan(e: CXmlToTable, cols: Sequence[Col]):
     ni, nu = ctypes.c_int(0), ctypes.c_int(0)
     capi.check(_lib().mdc_bind_plan(ctypes.byref(e), cc, len(cols), ins, ctypes.byref(ni), upd, ctypes.byref(nu)))
     return list(ins[:ni.value]), list(upd[:nu.value])
+
+
+def slab_rows(slab: CBindSlab, nrows: int) -> List[bytes]:
+    """The texts of one bound column, row by row (each slot up to its NUL)."""
+    import numpy as np
+    if nrows == 0:
+        return []
+    buf = (ctypes.c_char * (nrows * slab.stride)).from_address(slab.base)
+    a = np.frombuffer(buf, dtype=np.uint8).reshape(nrows, slab.stride)
+    return [bytes(r).split(b"\0")[0] for r in a]
+
+
+def ingest_rows(ins: Sequence[CBindSlab], upd: Sequence[CBindSlab], rows: int, uptbz: int, execute) -> CIngestCounts:
+    """mdc_ingest_rows: `execute(statement, columns, nrows)` gets the bound texts as a list of columns (each a
+    list of nrows byte strings) and returns the per-row database codes (0 = done, 1 = ORA-00001 ...), or None
+    when the statement could not be executed at all."""
+    L = _lib()
+
+    def thunk(ctx, statement, slabs, nslabs, nrows, rowcode):
+        cols = [slab_rows(slabs[k], nrows) for k in range(nslabs)]
+        codes = execute(statement, cols, nrows)
+        if codes is None:
+            return 1
+        for r in range(nrows):
+            rowcode[r] = int(codes[r])
+        return 0
+
+    cb = ARRAY_EXEC(thunk)
+    ia = (CBindSlab * max(1, len(ins)))(*ins)
+    ua = (CBindSlab * max(1, len(upd)))(*upd)
+    counts = CIngestCounts()
+    capi.check(L.mdc_ingest_rows(ia, len(ins), ua if len(upd) else None, len(upd), rows, uptbz, cb, None, ctypes.byref(counts)))
+    return counts
+
+
+def batch_bind_slabs(batch, entry, cols: Sequence[Col]):
+    """mdc_batch_bind_slabs: (insert slabs, update slabs) of a parsed batch."""
+    L = _lib()
+    n = len(cols)
+    ins, upd = (CBindSlab * n)(), (CBindSlab * n)()
+    ni, nu = ctypes.c_int(0), ctypes.c_int(0)
+    ent = entry
+    capi.check(L.mdc_batch_bind_slabs(batch.h, ctypes.byref(ent), c_cols(cols), n, ins, ctypes.byref(ni), upd, ctypes.byref(nu)))
+    return list(ins[: ni.value]), list(upd[: nu.value])

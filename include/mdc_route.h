@@ -81,6 +81,55 @@ int mdc_crtsql(const mdc_xmltotable *entry, const mdc_col *cols, int ncols, char
 int mdc_bind_plan(const mdc_xmltotable *entry, const mdc_col *cols, int ncols, int *ins, int *nins,
                   int *upd, int *nupd);
 
+/* ---- the execute loop of a file in bulk (tools/xmltodb.cpp:263-306) ----------------------
+ *
+ * The reference runs, per record: insert; on ORA-00001 (sqlstatement::rc() == 1) and uptbz == 1
+ * the update; any other failure is logged and the loop goes on, except ORA-03113, 03114, 03135
+ * and 16014 (the connection is gone), which end the file with code 2 before the commit; after the
+ * last record: commit, code 0.  With array binds the same decisions are taken once per file:
+ * one array insert of every row, the rows it rejected as duplicates gathered (in row order) into
+ * the update statement's bind order, one array update of those, then the commit by the caller.
+ * The database ends in the same state: a row's update still follows its own insert attempt and
+ * precedes the update of any later row, and a lost connection leaves nothing committed. */
+
+/* One bound column as fixed-stride NUL-terminated slots (see mdc_batch_column_fixed). */
+typedef struct mdc_bind_slab {
+    const char *base;
+    size_t stride;
+    int col; /* index of the schema column */
+    int pad;
+} mdc_bind_slab;
+
+/* The slabs of a parsed batch in the bind order of the two statements (mdc_bind_plan): ins[k] is
+ * bound to :k+1 of the insert, upd[k] to :k+1 of the update (filled when entry->uptbz == 1, else
+ * *nupd = 0).  Both arrays need room for ncols entries; the memory belongs to the batch. */
+int mdc_batch_bind_slabs(mdc_batch *b, const mdc_xmltotable *entry, const mdc_col *cols, int ncols,
+                         mdc_bind_slab *ins, int *nins, mdc_bind_slab *upd, int *nupd);
+
+/* The caller's array execute (OCIStmtExecute with iters = nrows in batch-error mode, or a loop of
+ * single executes): statement 0 = insert, 1 = update; slabs[k] row r is the text bound to :k+1 for
+ * that row; rowcode[r] receives 0 for a row that went through, else the database's error number
+ * (1 = ORA-00001).  A nonzero return means the statement could not be executed at all. */
+typedef int (*mdc_array_exec)(void *ctx, int statement, const mdc_bind_slab *slabs, int nslabs, int64_t nrows,
+                              int *rowcode);
+
+typedef struct mdc_ingest_counts {
+    int64_t totalcount; /* records of the file (tools/xmltodb.cpp:266)                        */
+    int64_t inscount;   /* inserted (:304)                                                     */
+    int64_t uptcount;   /* updated after a duplicate (:287)                                    */
+    int64_t insfailed;  /* insert failed for another reason (the reference logs them, :291-295) */
+    int64_t uptfailed;  /* update failed (logged, :281-286)                                    */
+    int64_t duplicates; /* inserts rejected with ORA-00001                                     */
+    int result;         /* _xmltodb()'s code: 0 = commit the file, 2 = database error, do not  */
+    int fatalcode;      /* the error number that ended the file when result == 2               */
+} mdc_ingest_counts;
+
+/* Runs the loop over `rows` rows given as slabs in both bind orders (upd may be NULL when
+ * uptbz != 1).  Returns MDC_OK whenever the decisions could be taken (look at counts->result);
+ * the commit or rollback stays with the caller, who owns the connection. */
+int mdc_ingest_rows(const mdc_bind_slab *ins, int nins, const mdc_bind_slab *upd, int nupd, int64_t rows, int uptbz,
+                    mdc_array_exec exec, void *ctx, mdc_ingest_counts *counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,211 @@
+"""The execute loop of a file in bulk (mdc_ingest_rows, include/mdc_route.h) against the reference's
+per-record loop (tools/xmltodb.cpp:263-306) restated over a mock table: insert, update on
+ORA-00001 when uptbz == 1, other failures logged, a lost connection ends the file with code 2.
+Counts, the return code and the table's final state must agree."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+from dsp_amd import capi, gen, route, schema
+
+COLS = schema.ZHOBTMIND
+FATAL = (3113, 3114, 3135, 16014)
+
+
+class MockTable:
+    """A table with the primary key (obtid, ddatetime): dates must be 14 digits (else ORA-01861), numbers
+    must read as numbers (else ORA-01722), the text b'LOST' in the key stands for a connection that is gone."""
+
+    def __init__(self, key_cols, date_cols, number_cols):
+        self.rows = {}
+        self.key_cols, self.date_cols, self.number_cols = key_cols, date_cols, number_cols
+        self.statements = 0
+
+    def _check(self, names, values):
+        for n, v in zip(names, values):
+            if v == b"LOST":
+                return 3113
+            if n in self.date_cols and not (len(v) == 14 and v.isdigit()):
+                return 1861
+            if n in self.number_cols and v:
+                try:
+                    float(v)
+                except ValueError:
+                    return 1722
+        return 0
+
+    def insert(self, names, values):
+        code = self._check(names, values)
+        if code:
+            return code
+        row = dict(zip(names, values))
+        key = tuple(row[k] for k in self.key_cols)
+        if key in self.rows:
+            return 1
+        self.rows[key] = row
+        return 0
+
+    def update(self, names, values):
+        code = self._check(names, values)
+        if code:
+            return code
+        row = dict(zip(names, values))
+        key = tuple(row[k] for k in self.key_cols)
+        if key in self.rows:
+            self.rows[key].update(row)
+        return 0  # (an update that matches no row is no error)
+
+
+def reference_loop(table, records, ins_names, upd_names, uptbz):
+    """tools/xmltodb.cpp:263-306, one record at a time; returns (code, totalcount, inscount, uptcount, logged)."""
+    total = ins = upt = logged = 0
+    for rec in records:
+        total += 1
+        rc = table.insert(ins_names, [rec[n] for n in ins_names])
+        if rc != 0:
+            if rc == 1:
+                if uptbz == 1:
+                    if table.update(upd_names, [rec[n] for n in upd_names]) != 0:
+                        logged += 1
+                    else:
+                        upt += 1
+            else:
+                logged += 1
+                if rc in FATAL:
+                    return 2, total, ins, upt, logged
+        else:
+            ins += 1
+    return 0, total, ins, upt, logged
+
+
+def make_slabs(records, names):
+    keep, slabs = [], []
+    for n in names:
+        col = next(c for c in COLS if c.colname == n)
+        a = np.zeros((max(1, len(records)), col.collen + 1), dtype=np.uint8)
+        for r, rec in enumerate(records):
+            v = rec[n][:col.collen]
+            a[r, :len(v)] = np.frombuffer(v, dtype=np.uint8)
+        keep.append(a)
+        slabs.append(route.CBindSlab(a.ctypes.data, col.collen + 1, [c.colname for c in COLS].index(n), 0))
+    return keep, slabs
+
+
+def plans(uptbz):
+    e = route.entry("ZHOBTMIND*.XML", "T_ZHOBTMIND1", uptbz, "")
+    bi, bu = route.bind_plan(e, COLS)
+    return [COLS[i].colname for i in bi], [COLS[i].colname for i in bu]
+
+
+def random_records(rng, n, keys):
+    out = []
+    for i in range(n):
+        k = rng.choice(keys)
+        rec = {"obtid": k[0], "ddatetime": k[1], "upttime": b"20240519000000", "keyid": b"%d" % (1000 + i)}
+        for name in ("t", "p", "u", "wd", "wf", "r", "vis"):
+            rec[name] = b"%d.%d" % (rng.randrange(-40, 1050), rng.randrange(10))
+        roll = rng.random()
+        if roll < 0.05:
+            rec["ddatetime"] = b"2024051916"          # not a date: ORA-01861 on insert
+        elif roll < 0.10:
+            rec["wf"] = b"1.2.3"                       # not a number
+        out.append(rec)
+    return out
+
+
+@pytest.mark.parametrize("uptbz", [1, 2])
+@pytest.mark.parametrize("seed", range(12))
+def test_bulk_loop_equals_the_per_record_loop(seed, uptbz):
+    rng = random.Random(seed)
+    keys = [(b"5%04d" % rng.randrange(10000), b"202405191628%02d" % s) for s in range(40)]
+    records = random_records(rng, rng.choice([0, 1, 7, 300]), keys)
+    if seed % 4 == 3 and records:   # the connection goes away somewhere in the file
+        records[rng.randrange(len(records))]["obtid"] = b"LOST"
+    ins_names, upd_names = plans(uptbz)
+    key_cols, date_cols = ["obtid", "ddatetime"], {"ddatetime", "upttime"}
+    number_cols = {c.colname for c in COLS if c.datatype == "number"}
+    # some rows are in the table already
+    pre = random_records(random.Random(1000 + seed), 15, keys)
+    t_ref, t_bulk = MockTable(key_cols, date_cols, number_cols), MockTable(key_cols, date_cols, number_cols)
+    for t in (t_ref, t_bulk):
+        for rec in pre:
+            t.insert(ins_names, [rec[n] for n in ins_names])
+    code, total, ins, upt, logged = reference_loop(t_ref, records, ins_names, upd_names, uptbz)
+
+    keep_i, slabs_i = make_slabs(records, ins_names)
+    keep_u, slabs_u = make_slabs(records, upd_names) if uptbz == 1 else ([], [])
+
+    def execute(statement, cols, nrows):
+        t_bulk.statements += 1
+        names = ins_names if statement == 0 else upd_names
+        codes = []
+        for r in range(nrows):
+            vals = [cols[k][r] for k in range(len(names))]
+            codes.append(t_bulk.insert(names, vals) if statement == 0 else t_bulk.update(names, vals))
+        return codes
+
+    c = route.ingest_rows(slabs_i, slabs_u, len(records), uptbz, execute)
+    assert c.result == code
+    assert c.totalcount == len(records)
+    if code == 0:
+        assert (c.totalcount, c.inscount, c.uptcount) == (total, ins, upt)
+        assert c.insfailed + c.uptfailed == logged
+        assert t_bulk.rows == t_ref.rows
+        assert t_bulk.statements <= 2
+    else:
+        # a lost connection: nothing is committed either way; the counts stop at that record as the reference's do
+        assert c.fatalcode in FATAL and c.inscount == ins and c.uptcount == 0
+
+
+def test_a_statement_that_cannot_run_is_a_database_error():
+    ins_names, upd_names = plans(1)
+    records = random_records(random.Random(5), 20, [(b"50001", b"20240519162800")])
+    keep, slabs = make_slabs(records, ins_names)
+    keep_u, slabs_u = make_slabs(records, upd_names)
+    c = route.ingest_rows(slabs, slabs_u, len(records), 1, lambda s, cols, n: None)
+    assert c.result == 2 and c.inscount == 0
+
+
+def test_arguments():
+    L = capi.lib()
+    route._lib()
+    counts = route.CIngestCounts()
+    cb = route.ARRAY_EXEC(lambda *a: 0)
+    assert L.mdc_ingest_rows(None, 0, None, 0, -1, 0, cb, None, ctypes.byref(counts)) == capi.MDC_ERR_ARG
+    assert L.mdc_ingest_rows(None, 0, None, 0, 0, 0, cb, None, None) == capi.MDC_ERR_ARG
+    assert L.mdc_ingest_rows(None, 0, None, 0, 0, 1, cb, None, ctypes.byref(counts)) == capi.MDC_OK and counts.totalcount == 0
+
+
+@pytest.mark.gpu
+def test_a_parsed_file_through_the_bulk_loop(port):
+    # the file twice over: every row of the second half is a duplicate of the first and takes the update
+    data, n = gen.mind_xml(rows=400)
+    body = bytes(data)
+    start, end = body.index(b"\n") + 1, body.rindex(b"</data>")
+    twice = np.frombuffer(body[:end] + body[start:end].replace(b"<u>", b"<u>1") + body[end:], dtype=np.uint8)
+    p = capi.Parser.xml(COLS)
+    b = p.parse_host(twice)
+    exp = port.parse_xml(twice, COLS)
+    assert b.rows == exp.rows == 2 * n
+    e = route.entry("ZHOBTMIND*.XML", "T_ZHOBTMIND1", 1, "")
+    ins, upd = route.batch_bind_slabs(b, e, COLS)
+    ins_names, upd_names = plans(1)
+    assert [COLS[s.col].colname for s in ins] == ins_names and [COLS[s.col].colname for s in upd] == upd_names
+    records = [{c.colname: exp.cell(r, i)[:c.collen] for i, c in enumerate(COLS)} for r in range(exp.rows)]
+    number_cols = {c.colname for c in COLS if c.datatype == "number"}
+    t_ref = MockTable(["obtid", "ddatetime"], {"ddatetime"}, number_cols)
+    t_bulk = MockTable(["obtid", "ddatetime"], {"ddatetime"}, number_cols)
+    code, total, ni, nu, logged = reference_loop(t_ref, records, ins_names, upd_names, 1)
+
+    def execute(statement, cols, nrows):
+        names = ins_names if statement == 0 else upd_names
+        return [(t_bulk.insert if statement == 0 else t_bulk.update)(names, [cols[k][r] for k in range(len(names))])
+                for r in range(nrows)]
+
+    c = route.ingest_rows(ins, upd, b.rows, 1, execute)
+    assert (c.result, c.totalcount, c.inscount, c.uptcount) == (code, total, ni, nu) == (0, 2 * n, n, n)
+    assert t_bulk.rows == t_ref.rows
+    b.free()
+    p.close()
