@@ -533,21 +533,19 @@ def test_delimited_long_batch_with_trim(port, bdel):
     assert_batches_equal(got, exp, "delimited, many tiles")
 
 
-def test_full_size_batch_equals_its_parts(port):
-    """1 GiB (the size the metric is quoted on): the parse of the whole batch equals the
-    concatenation of the parses of four parts cut at record terminators, and the first part's
-    head equals the CPU checker; rows match the generator's count."""
+def _whole_equals_parts_and_checker_windows(port, data, n, p, parse_window, endbz, nwindows=6, window=4 << 20):
+    """The parse of the whole batch equals the concatenation of the parses of four parts cut at record
+    terminators (rows match the generator's count), and windows of the batch spread over its whole length,
+    cut at record boundaries and parsed by the CPU checker, equal the rows of the whole parse they cover."""
     from dsp_amd import shard
 
-    data, n = gen.mind_xml(nbytes=int(os.environ.get("MDC_FULL_BYTES", 1 << 30)))  # (a larger batch on request)
-    p = capi.Parser.xml(schema.ZHOBTMIND)
     whole_b = p.parse_host(data)
     assert whole_b.rows == n
     whole = whole_b.to_host()
     whole_b.free()
     row = 0
     pos = [0] * whole.ncols
-    for lo, hi in shard.split_points(data, 4):
+    for lo, hi in shard.split_points(data, 4, endbz=endbz):
         b = p.parse_host(data[lo:hi])
         part = b.to_host()
         b.free()
@@ -564,12 +562,54 @@ def test_full_size_batch_equals_its_parts(port):
                 assert np.array_equal(part.val[c][:m], whole.val[c][row: row + m]), c
             pos[c] += nb
         row += m
+        del part
     assert row == n
-    cut = int(np.flatnonzero(data[: 4 << 20] == 10)[-1]) + 1
-    exp = port.parse_xml(np.ascontiguousarray(data[:cut]), schema.ZHOBTMIND)
-    for c in range(exp.ncols):
-        assert np.array_equal(whole.off[c][: exp.rows + 1], exp.off[c])
-        assert np.array_equal(whole.data[c][: int(exp.off[c][exp.rows])], exp.data[c])
+    # windows against the CPU checker: window k starts at the first record that begins at or behind k/nwindows of the batch
+    for k in range(nwindows):
+        want = len(data) * k // nwindows
+        r0 = int(np.searchsorted(whole.rec_off, want, side="left"))
+        if r0 >= n:
+            continue
+        lo = int(whole.rec_off[r0])
+        r1 = int(np.searchsorted(whole.rec_off, min(lo + window, len(data)), side="right")) - 1
+        hi = int(whole.rec_off[r1])
+        if k == 0:
+            lo = 0  # (the bytes in front of the first record belong to it: "<data>\n")
+        exp = parse_window(np.ascontiguousarray(data[lo:hi]))
+        m = exp.rows
+        assert m == r1 - r0 and m > 0, (k, m, r1 - r0)
+        assert np.array_equal(exp.found, whole.found[r0: r0 + m]), k
+        assert np.array_equal(exp.valid, whole.valid[r0: r0 + m]), k
+        for c in range(exp.ncols):
+            base = whole.off[c][r0].astype(np.uint64)
+            assert np.array_equal(exp.off[c].astype(np.uint64) + base, whole.off[c][r0: r0 + m + 1].astype(np.uint64)), (k, c)
+            assert np.array_equal(exp.data[c], whole.data[c][int(base): int(base) + int(exp.off[c][m])]), (k, c)
+            if exp.val[c] is not None:
+                assert np.array_equal(exp.val[c], whole.val[c][r0: r0 + m]), (k, c)
+
+
+def test_full_size_batch_equals_its_parts(port):
+    """1 GiB of tagged records: the size the metric is quoted on (MDC_FULL_BYTES: a larger batch on request)."""
+    data, n = gen.mind_xml(nbytes=int(os.environ.get("MDC_FULL_BYTES", 1 << 30)))
+    p = capi.Parser.xml(schema.ZHOBTMIND)
+    _whole_equals_parts_and_checker_windows(port, data, n, p, lambda d: port.parse_xml(d, schema.ZHOBTMIND), "<endl/>")
+    p.close()
+
+
+def test_full_size_delimited_batch_equals_its_parts(port):
+    """4 GiB of delimited records: the size of the delimited configuration (MDC_FULL_CSV_BYTES: another size)."""
+    from concurrent.futures import ThreadPoolExecutor
+    nbytes = int(os.environ.get("MDC_FULL_CSV_BYTES", 4 << 30))
+    part = 256 << 20
+    sizes = [min(part, nbytes - i * part) for i in range((nbytes + part - 1) // part)]
+    with ThreadPoolExecutor(max_workers=16) as ex:  # (the generator is C code that runs without the interpreter lock)
+        made = list(ex.map(lambda i: gen.mind_csv(nbytes=sizes[i], first_row=i * 5_000_000), range(len(sizes))))
+    data = np.concatenate([m[0] for m in made]) if len(made) > 1 else made[0][0]
+    n = sum(m[1] for m in made)
+    del made
+    typed = schema.MIND_CSV_TYPED
+    p = capi.Parser.csv(",", 10, typed=typed)
+    _whole_equals_parts_and_checker_windows(port, data, n, p, lambda d: port.parse_csv(d, ",", 10, typed=typed), "")
     p.close()
 
 
