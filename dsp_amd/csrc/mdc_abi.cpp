@@ -306,7 +306,7 @@ static void compute_emit_layout(uint32_t ncols, uint32_t words, uint32_t lbmax, 
         L.colout = o;
         o += round16(ncols * 32);
         L.schema = o;
-        o += (uint32_t)sizeof(SchemaHdr) + round16(ncols * (uint32_t)sizeof(DevCol)) + 192;  // header, columns, 10^k
+        o += (uint32_t)sizeof(SchemaHdr) + round16(ncols * (uint32_t)sizeof(DevCol)) + P10_TABLE_DOUBLES * 8;  // header, columns, 10^k
         L.total = o;
         L.RB = RB;
         if (o <= LDS_FIVE_BLOCKS || RB <= 8) break;
@@ -451,7 +451,7 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
 
     const size_t cols_bytes = (ncols * sizeof(DevCol) + 15) & ~(size_t)15;
     const size_t p10_off = sizeof(SchemaHdr) + cols_bytes + ht.size() * sizeof(HtEntry);
-    p->blob.assign(p10_off + 23 * sizeof(double) + 8, 0);
+    p->blob.assign(p10_off + P10_TABLE_DOUBLES * sizeof(double), 0);
     p->blob.resize((p->blob.size() + 15) & ~(size_t)15);
     SchemaHdr *H = (SchemaHdr *)p->blob.data();
     H->ncols = ncols;
@@ -476,6 +476,14 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
     for (int k = 0; k < 23; ++k) {
         memcpy(p->blob.data() + p10_off + 8 * k, &p10, 8);
         p10 *= 10.0;  // exact up to 1e22
+    }
+    // behind them (16-byte aligned): the pairs {10^k, 1 / 10^k rounded to nearest} for k < P10_PAIRS
+    p10 = 1.0;
+    for (int k = 0; k < P10_PAIRS; ++k) {
+        const double r = 1.0 / p10;
+        memcpy(p->blob.data() + p10_off + 8 * (P10_PAIR_AT + 2 * k), &p10, 8);
+        memcpy(p->blob.data() + p10_off + 8 * (P10_PAIR_AT + 2 * k + 1), &r, 8);
+        p10 *= 10.0;
     }
     for (int lv = 0; lv < 3; ++lv) {
         compute_layout(ncols, npat, p->words, (uint32_t)p->blob.size(), LB_LEVELS[lv], p->Ls[lv]);

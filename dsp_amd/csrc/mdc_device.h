@@ -22,6 +22,12 @@ constexpr int MAX_COLS = 128;
 constexpr int MAX_ENDBZ = 32;
 constexpr int MAX_SEP = 16;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+// The table of powers of ten at SchemaHdr::p10_off (16-byte aligned): double[23] = 10^0 .. 10^22, one
+// double of padding, then P10_PAIRS pairs {10^k, 1 / 10^k} (the quotient of an integer below 10^8 by
+// 10^k, k <= 8, is taken with one multiplication and one correction step: see cell_simple).
+constexpr int P10_PAIR_AT = 24;
+constexpr int P10_PAIRS = 9;
+constexpr int P10_TABLE_DOUBLES = P10_PAIR_AT + 2 * P10_PAIRS;  // 42: a multiple of two doubles
 constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)2 << 20;  // static device scratch of mdc_parse_device_noalloc
 // Tag template (tagged input): the '<' events of one sample record, in order.  Event k of a
 // record whose events all repeat the sample's tag texts byte for byte matches what sample event
