@@ -2040,6 +2040,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 P.found[row * W + w] = fmask[tid * W + w];
             }
         }
+        if (rb0 + RB >= nrec) break;  // (the totals below are read behind the barrier that follows the cells)
         __syncthreads();
         STAMP(9);  // row outputs
         if (tid == 0) {
@@ -2061,7 +2062,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         if (tid == 0) {
             tc[ncols] = nrec_all;
             if (P.tile_hdr) {
-                // all batches are done (the loop ends with a barrier): is the tile's map complete?
+                // all batches are done (a barrier follows the last batch's cells): is the tile's map complete?
                 const uint32_t slot = map_slot;
                 const bool mapped = slot != NONE && !ms[MS_NOMAP];
                 P.tile_hdr[2 * blockIdx.x] = mapped ? slot : longrec ? HDR_LONGREC : NONE;
@@ -2219,6 +2220,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             for (uint32_t r = lane; r < RBn; r += 64) mapl[c * RB + r] = mp[r];
         }
     };
+    auto clear_masks = [&]() {
+        for (uint32_t i = tid; i < RB * W; i += BLOCK) {
+            vmask[i] = 0;
+            fmask[i] = 0;
+        }
+    };
+    clear_masks();
     __syncthreads();
     const SchemaHdr *H = (const SchemaHdr *)(smem + L.schema);
     const DevCol *cols = (const DevCol *)(H + 1);
@@ -2240,12 +2248,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     bool deferred = false, overrun = false;
     for (uint32_t rb0 = 0; rb0 < nrec; rb0 += RB) {
         const uint32_t RBn = (nrec - rb0 < RB) ? nrec - rb0 : RB;
-        if (rb0) load_map(rb0, RBn);  // (the previous batch ended with a barrier)
-        for (uint32_t i = tid; i < RB * W; i += BLOCK) {
-            vmask[i] = 0;
-            fmask[i] = 0;
+        if (rb0) {  // (the previous batch ended with a barrier; the first batch was set up above)
+            load_map(rb0, RBn);
+            clear_masks();
+            __syncthreads();
         }
-        __syncthreads();  // also orders the bitmap and the previous batch's row outputs
         for (uint32_t c = wave; c < ncols && !SKIP(16); c += BLOCK / 64) {
             const uint32_t *mp = mapl + c * RB;
             uint32_t cs_[RB_PASSES], cl_[RB_PASSES], cv_[RB_PASSES];
@@ -2279,10 +2286,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
                 P.found[row * W + w] = fmask[tid * W + w];
             }
         }
-        __syncthreads();
+        if (rb0 + RB < nrec) __syncthreads();  // the next batch reuses the map and the bitmaps
     }
     if (deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
-    // (the batch loop ends with a barrier) every column must have come out as long as it was sized
+    // (behind the barrier that follows the last batch's columns) every column must have come out
+    // as long as it was sized
     bool differ = overrun;
     for (uint32_t c = tid; c < ncols; c += BLOCK) differ |= tiletot[c] != sized[c];
     if (differ) atomicOr(P.status, ST_INTERNAL);
