@@ -1053,6 +1053,31 @@ __device__ __forceinline__ void win_store(uint8_t *dst, uint64_t lo, uint64_t hi
     if (n & 1) *dst = (uint8_t)lo;
 }
 
+// ORs the first n (<= 16; WIDE: some cell of the wave has more than 8) bytes of the window into a
+// cleared LDS area at byte x: the bytes are shifted to x's place within aligned words (one byte
+// permute per word) and go in with aligned word ORs, which neighbouring cells sharing a word
+// may do in any order.  No branch on n, no unaligned access.
+template <bool WIDE>
+__device__ __forceinline__ void win_or(uint8_t *area, uint32_t x, uint64_t lo, uint64_t hi, uint32_t n) {
+    const uint32_t nlo = n < 8 ? n : 8;
+    lo &= nlo < 8 ? ~(~0ull << (8 * nlo)) : ~0ull;
+    const uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32);
+    const uint32_t sel = 0x07060504u - 0x01010101u * (x & 3);  // byte i of a word: byte 4 - (x & 3) + i of (word, word before)
+    uint32_t *p = (uint32_t *)(area + (x & ~3u));
+    atomicOr(p, __builtin_amdgcn_perm(w0, 0u, sel));
+    atomicOr(p + 1, __builtin_amdgcn_perm(w1, w0, sel));
+    if (!WIDE) {
+        atomicOr(p + 2, __builtin_amdgcn_perm(0u, w1, sel));
+    } else {
+        const uint32_t nhi = n - nlo;
+        hi &= nhi < 8 ? ~(~0ull << (8 * nhi)) : ~0ull;
+        const uint32_t w2 = (uint32_t)hi, w3 = (uint32_t)(hi >> 32);
+        atomicOr(p + 2, __builtin_amdgcn_perm(w2, w1, sel));
+        atomicOr(p + 3, __builtin_amdgcn_perm(w3, w2, sel));
+        atomicOr(p + 4, __builtin_amdgcn_perm(0u, w3, sel));
+    }
+}
+
 constexpr int RB_PASSES = 2;  // records per batch <= 64 * RB_PASSES
 
 // descriptor of one cell: source start (15 bits) | source length (15 bits) | filter level (2)
@@ -1226,11 +1251,11 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
         }
         // the cells' bytes go to `base` + their offset in the batch; called once per destination
         // so that LDS and global stores are told apart at compile time
-        auto put_cells = [&](uint8_t *base) {
+        auto put_cells = [&](uint8_t *base, bool others) {  // others: only the cells that are not fast ones
 #pragma unroll
             for (int ps = 0; ps < RB_PASSES; ++ps) {
                 const uint32_t r = ps * 64 + lane;
-                if (r < RBn && cf_[ps]) {
+                if (r < RBn && cf_[ps] && !(others && cfast_[ps])) {
                     uint8_t *dst = base + cx_[ps];
                     uint64_t dv;
                     bool b1;
@@ -1250,7 +1275,28 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
         if (E.dbg & 128) return total;
 #endif
         if (staged) {
-            put_cells(E.wstage + a);
+            // fast cells (their bytes are in registers) are ORed into the cleared area, the others
+            // are stored byte by byte behind them (LDS takes a wave's instructions in order)
+            for (uint32_t u = lane; u < (a + total + 15) / 16; u += 64) ((uint4 *)E.wstage)[u] = make_uint4(0, 0, 0, 0);
+            bool wide = false, others = false;
+            uint32_t nf_[RB_PASSES];
+#pragma unroll
+            for (int ps = 0; ps < RB_PASSES; ++ps) {
+                const bool act = ps * 64 + (uint32_t)lane < RBn && cf_[ps];
+                nf_[ps] = act && cfast_[ps] ? cf_[ps] : 0u;
+                others |= act && !cfast_[ps];
+                wide |= nf_[ps] > 8;
+            }
+            if (__builtin_amdgcn_ballot_w64(wide) == 0) {
+#pragma unroll
+                for (int ps = 0; ps < RB_PASSES; ++ps)
+                    if (nf_[ps]) win_or<false>(E.wstage, a + cx_[ps], clo_[ps], chi_[ps], nf_[ps]);
+            } else {
+#pragma unroll
+                for (int ps = 0; ps < RB_PASSES; ++ps)
+                    if (nf_[ps]) win_or<true>(E.wstage, a + cx_[ps], clo_[ps], chi_[ps], nf_[ps]);
+            }
+            if (__builtin_amdgcn_ballot_w64(others)) put_cells(E.wstage + a, true);
 #ifdef MDC_ABLATE
             if (E.dbg & 256) return total;
 #endif
@@ -1268,7 +1314,7 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
                 if ((uint32_t)lane < total - done) dst[done + lane] = src[done + lane];
             }
         } else {
-            put_cells((uint8_t *)(bytesp + gb));
+            put_cells((uint8_t *)(bytesp + gb), false);
         }
     }
     return total;
