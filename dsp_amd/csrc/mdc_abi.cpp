@@ -182,6 +182,7 @@ struct mdc_parser {
     void *d_blob = nullptr;
     LdsLayout Ls[3]{};  // one layout per look-behind level
     LdsLayout LEs[3]{}; // ... and the emit kernel's
+    LdsLayout LEd[3]{}; // ... for inputs of short records
     LdsLayout LSs[3]{}; // ... and the sizing pass's
     int lb_level = 0;   // level that fitted the previous parse
     // workspace
@@ -244,16 +245,19 @@ static const uint32_t LDS_FIVE_BLOCKS = 31 * 1024 + 256;
 // lean = the sizing pass of tagged input: it keeps no event list, stages no cells and needs no
 // output pointers, which is worth a sixth block per CU
 static const uint32_t LDS_SIX_BLOCKS = 25 * 1024 + 512;
+// sizing = the sizing pass (it needs no output pointers and no table of powers of ten; blob_bytes is
+// the schema without that table); of delimited input it takes batches of up to 128 records where
+// they fit, since such records are short (a list of 2,568 instead of 3,072 separators pays for that).
 static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32_t blob_bytes, uint32_t lbmax,
-                           LdsLayout &L, bool lean = false) {
-    uint32_t RB = 112;
+                           LdsLayout &L, bool lean = false, bool sizing = false) {
+    uint32_t RB = sizing && !npat ? 128 : 112;
     for (;;) {
         uint32_t o = 0;
         L.lbmax = lbmax;
         L.data = o;
         o += round16(TILE + lbmax + DATA_SLACK);
         L.evlist = o;
-        L.evcap = lean ? 0 : npat ? 1280 : 2048;  // staging area of the full write kernel; separators of a tile
+        L.evcap = lean ? 0 : npat ? 1280 : sizing ? 1712 : 2048;  // staging area of the full write kernel; separators of a tile
         L.stage_cap = L.evcap * 3;
         o += L.evcap * 3;
         L.evt = o;
@@ -268,7 +272,7 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         L.coltot = o;
         o += round16(2 * (ncols + 1) * 4);
         L.colout = o;
-        if (!lean) o += round16(ncols * 32);
+        if (!lean && !sizing) o += round16(ncols * 32);
         L.schema = o;
         o += round16(blob_bytes);
         L.misc = o;
@@ -283,8 +287,10 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
 
 // The emit kernel's LDS: tile image, map slice (in `evt`), staging (in `evlist`), masks,
 // schema; small enough for five blocks per CU at the first look-behind level.
-static void compute_emit_layout(uint32_t ncols, uint32_t words, uint32_t lbmax, LdsLayout &L) {
-    uint32_t RB = 112;
+// dense = for inputs of short records (more than a hundred to a tile): batches of 128 records, paid
+// for with a smaller staging area (their cells are short as well).
+static void compute_emit_layout(uint32_t ncols, uint32_t words, uint32_t lbmax, LdsLayout &L, bool dense = false) {
+    uint32_t RB = dense ? 128 : 112;
     for (;;) {
         uint32_t o = 0;
         L = LdsLayout{};
@@ -293,7 +299,7 @@ static void compute_emit_layout(uint32_t ncols, uint32_t words, uint32_t lbmax, 
         o += round16(TILE + lbmax + DATA_SLACK);
         L.evlist = o;
         L.evcap = 0;
-        L.stage_cap = 6144;
+        L.stage_cap = dense ? 5120 : 6144;
         o += L.stage_cap;
         L.evt = o;
         o += round16(RB * (ncols + 1) * 4);
@@ -488,7 +494,8 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
     for (int lv = 0; lv < 3; ++lv) {
         compute_layout(ncols, npat, p->words, (uint32_t)p->blob.size(), LB_LEVELS[lv], p->Ls[lv]);
         compute_emit_layout(ncols, p->words, LB_LEVELS[lv], p->LEs[lv]);
-        compute_layout(ncols, npat, p->words, (uint32_t)p->blob.size(), LB_LEVELS[lv], p->LSs[lv], npat != 0);
+        compute_emit_layout(ncols, p->words, LB_LEVELS[lv], p->LEd[lv], true);
+        compute_layout(ncols, npat, p->words, ((const SchemaHdr *)p->blob.data())->p10_off, LB_LEVELS[lv], p->LSs[lv], npat != 0, true);
         if (p->Ls[lv].total > 160 * 1024)
             return fail(MDC_ERR_ARG, "schema too large for LDS (%u bytes)", p->Ls[lv].total);
     }
@@ -791,7 +798,9 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         HIP_TRY(hipEventRecord(p->ev[0], s));
         const bool build_tmpl = P.use_tmpl && !p->tmpl_valid && ntiles;
         if (build_tmpl) HIP_TRY(launch_template_kernel(P, s));
+        P.schema_bytes = P.p10_off;  // (the sizing pass converts nothing: the schema without the powers of ten)
         HIP_TRY(launch_tile_kernel(false, P, s));
+        P.schema_bytes = (uint32_t)p->blob.size();
         if (p->skew_tile >= 0 && (size_t)p->skew_tile < ntiles && p->skew_col >= 0 && p->skew_col < (int)ncols) {
             uint32_t *w = d_counts + (size_t)p->skew_tile * ncnt + p->skew_col, v = 0;
             HIP_TRY(hipStreamSynchronize(s));
@@ -955,7 +964,13 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
     P.found = o_found;
     HIP_TRY_B(hipEventRecord(p->ev[2], s));
     // tiles with a complete cell map take the short write kernel, the others the full one
-    P.L = p->LEs[p->lb_level];
+    {
+        const LdsLayout &d = p->LEd[p->lb_level], &n = p->LEs[p->lb_level];
+        // batches per tile at the input's mean record count: the layout that needs fewer of them
+        const uint64_t per_tile = ntiles ? (rows + ntiles - 1) / ntiles : 0;
+        const bool dense = d.RB > n.RB && (per_tile + d.RB - 1) / d.RB < (per_tile + n.RB - 1) / n.RB;
+        P.L = dense ? d : n;
+    }
     hipError_t le = launch_emit_kernel(P, s);
     P.L = p->Ls[p->lb_level];
     if (le == hipSuccess && unmapped) {
