@@ -476,6 +476,9 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
     if (el <= 8) memcpy(H->endbz_tail + 8 - el, endbz, el);
     H->sep_len = (uint32_t)sl;
     if (sl) memcpy(H->sep, sep, sl);
+    H->sep_fast = sl >= 1 && sl <= 4;
+    for (size_t k = 0; k < sl && k < 4; ++k)
+        if ((uint8_t)sep[k] >= 0x80 || sep[k] == '\n') H->sep_fast = 0;
     memcpy(p->blob.data() + sizeof(SchemaHdr), dc.data(), ncols * sizeof(DevCol));
     memcpy(p->blob.data() + sizeof(SchemaHdr) + cols_bytes, ht.data(), ht.size() * sizeof(HtEntry));
     double p10 = 1.0;

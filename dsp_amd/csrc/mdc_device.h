@@ -113,7 +113,8 @@ struct SchemaHdr {
     uint8_t sep[MAX_SEP];
     uint8_t endbz_tail[8];  // endbz right-aligned in 8 bytes (when endbz_len <= 8)
     int32_t tz_offset;      // MDC_T_TIME columns: seconds east of UTC of the zone mktime would run in
-    uint8_t pad4[4];
+    uint8_t sep_fast;       // delimited mode: the separator (1 to 4 bytes below 0x80, no '\n') is found with byte masks
+    uint8_t pad3[3];
     // followed by DevCol[ncols], HtEntry[ht_mask+1+chained] (16-byte aligned), double[23]
 };
 static_assert(sizeof(SchemaHdr) % 16 == 0, "SchemaHdr must keep 16-byte alignment");

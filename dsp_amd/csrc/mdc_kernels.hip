@@ -180,6 +180,7 @@ enum {
     MS_IRR = 10,    // sizing pass: a record of the tile does not follow the tag template
     MS_T0 = 11,     // long first record: LDS index of the first terminator of the tile
     MS_LONGE = 12,  // long first record: its entry in the list of long records
+    MS_SEPOV = 13,  // delimited mode: two separator matches of the tile overlap
     MS_COUNT = 16
 };
 
@@ -1421,9 +1422,9 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     const HtEntry *ht = (const HtEntry *)((const uint8_t *)cols + ((ncols * sizeof(DevCol) + 15) & ~15u));
     const bool csv = H->mode == MODE_CSV;
     const bool carry = H->carry != 0;
-    // delimited mode, sizing pass, one-byte separator: separators are collected like tag events
-    // and the field descriptors are made in parallel (otherwise: one lane walks each record)
-    const bool sepfast = csv && !WRITE && H->sep_len == 1 && H->sep[0] < 0x80;
+    // delimited mode, sizing pass, a separator of at most four bytes: separators are collected like tag
+    // events and the field descriptors are made in parallel (otherwise: one lane walks each record)
+    const bool sepfast = csv && !WRITE && H->sep_fast;
     // tagged input, sizing pass: records that repeat the sample record's tags take the template
     const bool tmode = !WRITE && !csv && P.use_tmpl && nT_in != 0 && nT_in <= tmpl_cap;
     const uint32_t nT = nT_in;
@@ -1481,6 +1482,40 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             const int b = __builtin_ctzll(nlm);
             nlm &= nlm - 1;
             if (is_term(sdata, H, base_pos, my_li + b)) tm |= 1ull << b;
+        }
+        if (sepfast && H->sep_len > 1) {
+            // A separator of several bytes: every match of its first byte is compared in full (a match
+            // that would pass the tile's end belongs to a record of the next tile).  The greedy search
+            // of ccmdstr::splittocmd (public/_public.cpp:274-302) goes on behind a separator it found,
+            // so of two matches that overlap ("~!~!~") it sees the first only: a tile with such a
+            // pair is left to the walk that does the same, all others may take every match.
+            const uint32_t sl = H->sep_len;
+            const uint32_t want = (uint32_t)H->sep[0] | ((uint32_t)H->sep[1] << 8) | ((uint32_t)H->sep[2] << 16) |
+                                  ((uint32_t)H->sep[3] << 24);
+            const uint32_t care = sl >= 4 ? ~0u : (1u << (8 * sl)) - 1;
+            auto match_at = [&](int li) {
+                uint32_t w0, w1;
+                lds_bytes8(sdata + li, w0, w1);
+                return ((w0 ^ want) & care) == 0;
+            };
+            uint64_t t = em, full = 0;
+            while (t) {
+                const int b = __builtin_ctzll(t);
+                t &= t - 1;
+                if (match_at(my_li + b)) full |= 1ull << b;
+            }
+            em = full;
+            uint64_t close = em << 1;
+            if (sl > 2) close |= em << 2;
+            if (sl > 3) close |= em << 3;
+            bool overlap = (em & close) != 0;
+            // ... and a match in the last bytes in front of this lane's that reaches one of this lane's
+            const uint32_t low = (uint32_t)em & ((1u << (sl - 1)) - 1);
+            if (low)
+                for (int d = 1; d < (int)sl; ++d)
+                    if (my_li - d >= li_min && my_li - d >= loaded_lo && (low & ((1u << (sl - d)) - 1)) && match_at(my_li - d))
+                        overlap = true;
+            if (overlap) ms[MS_SEPOV] = 1;
         }
     }
     if (tile_start > 0) search_terminators(loaded_lo, ts_li);
@@ -1612,7 +1647,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     if (tid == 0) recend[0] = (uint32_t)(s0_li - 1);
     const uint32_t seplen = H->sep_len;
     // all separators of the tile, in input order (the staging area is not used by the sizing pass)
-    const bool fastcsv = sepfast && nev_tile <= EVCAP + EVCAP / 2;
+    const bool fastcsv = sepfast && nev_tile <= EVCAP + EVCAP / 2 && !ms[MS_SEPOV];
     const bool slow0 = fastcsv && s0_li < ts_li;  // the first record starts in the look-behind: walked by one lane
     uint32_t *e0 = desc + ncols * RB;             // first separator of every record of the batch (RB + 1 entries)
     if (fastcsv) {
@@ -1763,7 +1798,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 const uint32_t first = e0[r], nsep = e0[r + 1] - first;
                 uint32_t fs = re, fl = 0;
                 if (c <= nsep) {
-                    fs = c ? (uint32_t)evpos[first + c - 1] + 1 : rs;
+                    fs = c ? (uint32_t)evpos[first + c - 1] + seplen : rs;
                     fl = (c < nsep ? (uint32_t)evpos[first + c] : re) - fs;
                     if (H->bdelspace) {
                         // deletelchr then deleterchr with its "pos != 0" test

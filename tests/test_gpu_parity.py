@@ -517,6 +517,50 @@ def test_delimited_tiles_dense_with_separators(port):
         assert_batches_equal(got, exp, "dense separators")
 
 
+@pytest.mark.parametrize("sep", ["~!~", "||", "aa", "::", ", ", "<->", "abab", "~~~~"])
+def test_separators_of_several_bytes_many_tiles(port, sep):
+    # the sizing pass finds separators of up to four bytes with byte masks; a tile in which two matches
+    # overlap ("~!~!~": the reference's search goes on behind the first) takes the walk instead
+    rng = np.random.default_rng(sum(sep.encode()))
+    alphabet = np.frombuffer((sep + "xyz01 .").encode(), dtype=np.uint8)
+    lines = []
+    for i in range(30000):
+        kind = i % 11
+        if kind == 3:  # bytes of the separator in any order: overlapping and partial matches
+            body = bytes(alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 60)))])
+        else:
+            f = [str(int(rng.integers(0, 10 ** int(rng.integers(1, 7))))) for _ in range(int(rng.integers(1, 8)))]
+            if kind == 5:
+                f[int(rng.integers(0, len(f)))] = ""
+            if kind == 7:
+                f.append(sep[:-1])  # a separator cut short at the end of the line
+            body = sep.join(f).encode()
+        lines.append(body.replace(b"\n", b" "))
+    data = b"\n".join(lines) + b"\n"
+    typed = [schema.T_I64, schema.T_F64, schema.T_NONE, schema.T_U32, schema.T_NONE]
+    for bdel in (False, True):
+        got = gpu_csv(data, sep, 5, typed=typed, bdelspace=bdel, ilen=[0, 0, 4, 0, 0])
+        exp = port.parse_csv(data, sep, 5, ilen=[0, 0, 4, 0, 0], typed=typed, bdelspace=bdel)
+        assert_batches_equal(got, exp, f"separator {sep!r}, bdelspace {bdel}")
+
+
+@pytest.mark.parametrize("sep", ["~!~", "aa", "abab"])
+def test_overlapping_separator_matches_at_every_place_of_a_lane(port, sep):
+    # a run of overlapping matches moved byte by byte across the 64-byte pieces the lanes classify, the
+    # waves' quarters of a tile and the tile's end
+    run = (sep * 3)[: 2 * len(sep) + 1].encode() if sep != "aa" else b"aaaaa"
+    p = capi.Parser.csv(sep, 4)
+    for at in list(range(16384 - 80, 16384 + 8)) + list(range(4096 - 70, 4096 + 6)):
+        head = b"1,2\n" * 3
+        pad = at - len(head) - 2
+        line = b"7" + sep.encode() + b"x" * (pad - 1 - len(sep)) + run + b"y" + sep.encode() + b"9\n"
+        data = head + line + b"5" + sep.encode() + b"6\n" * 1 + (b"3" + sep.encode() + b"4\n") * 50
+        got = p.parse_host(data).to_host()
+        exp = port.parse_csv(data, sep, 4)
+        assert_batches_equal(got, exp, f"separator {sep!r}, run at {at}")
+    p.close()
+
+
 @pytest.mark.parametrize("bdel", [False, True])
 def test_delimited_long_batch_with_trim(port, bdel):
     rng = np.random.default_rng(5)
