@@ -2374,7 +2374,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     // as long as it was sized
     bool differ = overrun;
     for (uint32_t c = tid; c < ncols; c += BLOCK) differ |= tiletot[c] != sized[c];
-    if (differ) atomicOr(P.status, ST_INTERNAL);
+    if (differ && !SKIP(16)) atomicOr(P.status, ST_INTERNAL);
 }
 
 // ---------------------------------------------------------------------------------------
