@@ -207,12 +207,12 @@ def copy_ceiling(device, src_ptr, nbytes, repeats=10):
         capi.lib().mdc_device_free(device, dst)
 
 
-def measured_traffic(kernel, nbytes):
+def measured_traffic(kernel, nbytes, name="traffic.json"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE and
     WRITE_SIZE need separate profiler runs, so they cannot be taken inside this process); only
     quoted when that profile was made on the same workload size."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", name)))
     except (OSError, ValueError):
         return None
     if t.get("workload_bytes") != nbytes or t.get("kernel") not in kernel:
@@ -346,7 +346,8 @@ def delimited_section(a, device):
                    "bytes": dbuf.n, "records": rows},
         "value": round(dbuf.n * steps / local_s / 1e9, 3), "unit": "GB/s", "steps": steps, "warmup": warmup,
         "ms_per_step": round(local_s / steps * 1e3, 4), "records_per_s": round(rows * steps / local_s, 1),
-        "roofline": roofline_of("mdc::emit_kernel (write pass)", dbuf.n, bytes_out, acc["write"] / steps, None),
+        "roofline": roofline_of("mdc::emit_kernel (write pass)", dbuf.n, bytes_out, acc["write"] / steps,
+                                measured_traffic("mdc::emit_kernel", dbuf.n, "traffic_delimited.json")),
         "kernel_ms": {"sizing_pass": round(acc["count"] / steps, 4), "scan": round(acc["scan"] / steps, 4),
                       "write_pass": round(acc["write"] / steps, 4), "device_total": round(acc["total"] / steps, 4)},
         "hbm_frac_whole_parse": round((dbuf.n + bytes_out) / (acc["total"] / steps * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
