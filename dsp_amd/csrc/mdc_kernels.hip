@@ -2158,7 +2158,9 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
 // search.  A block loads its tile (and the head of its first record from the look-behind),
 // rebuilds the digit bitmap, reads each cell's source from the map and runs the same column
 // routine as the tile kernel.  Tiles without a map are left to tile_kernel<true>.
-template <bool SPECIAL>
+// MANY: the instance for inputs whose tiles take several batches (batches of a multiple of 64 records):
+// later batches' map words come straight into LDS, see below.
+template <bool SPECIAL, bool MANY>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void emit_kernel(const TileParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     const LdsLayout &L = P.L;
@@ -2301,6 +2303,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             for (uint32_t r = lane; r < RBn; r += 64) mapl[c * RB + r] = mp[r];
         }
     };
+    // With rows of a multiple of 64 slots a later batch's map words come straight into LDS (no
+    // register is held while they are on their way): every wave fetches the rows it reads itself, its
+    // columns' when it begins its last column of the batch and its 64 record ends behind the row
+    // outputs.  The words are wave-private, so no barrier stands between their arrival and their use,
+    // only the wave's own wait.  (A lane beyond the next batch's records fetches the last record's word.)
+    constexpr bool dma = MANY;
+    auto dma_row = [&](uint32_t c, uint32_t h, uint32_t nrb0, uint32_t nRBn) {
+        const uint32_t r = h + lane;
+        const uint32_t *src = P.cellmap + (uint64_t)c * P.map_cap + slot + nrb0 + (r < nRBn ? r : nRBn - 1);
+        // (written out: the compiler, told of such a load, waits for every outstanding store in front of each
+        // later LDS read; the wait that counts is the one at the head of the next batch)
+        const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(mapl + c * RB + h));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src), "s"(dst) : "memory", "m0");
+    };
     auto clear_masks = [&]() {
         for (uint32_t i = tid; i < RB * W; i += BLOCK) {
             vmask[i] = 0;
@@ -2329,10 +2345,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     bool deferred = false, overrun = false;
     for (uint32_t rb0 = 0; rb0 < nrec; rb0 += RB) {
         const uint32_t RBn = (nrec - rb0 < RB) ? nrec - rb0 : RB;
+        const bool more = rb0 + RB < nrec;
+        const uint32_t nRBn = more ? (nrec - rb0 - RB < RB ? nrec - rb0 - RB : RB) : 0;  // records of the next batch
         if (rb0) {  // (the previous batch ended with a barrier; the first batch was set up above)
-            load_map(rb0, RBn);
-            clear_masks();
-            __syncthreads();
+            if (dma) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's rows have arrived
+            } else {
+                load_map(rb0, RBn);
+                clear_masks();
+                __syncthreads();
+            }
         }
         for (uint32_t c = wave; c < ncols && !SKIP(16); c += BLOCK / 64) {
             const uint32_t *mp = mapl + c * RB;
@@ -2348,6 +2370,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
                 fd_[ps] = (d >> 31) != 0;
                 if (fd_[ps]) atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
             }
+            if (dma && more && c + BLOCK / 64 >= ncols)  // the wave's last column: its rows of this batch are read
+                for (uint32_t cc = wave; cc < ncols; cc += BLOCK / 64)
+                    for (uint32_t h = 0; h < RB; h += 64) dma_row(cc, h, rb0 + RB, nRBn);
             const ColOut O = colout[c];
             const uint32_t done = tiletot[c];
             const uint64_t gb = O.base + done;
@@ -2365,9 +2390,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             for (uint32_t w = 0; w < W; ++w) {
                 P.valid[row * W + w] = vmask[tid * W + w];
                 P.found[row * W + w] = fmask[tid * W + w];
+                if (dma) {  // (for the next batch)
+                    vmask[tid * W + w] = 0;
+                    fmask[tid * W + w] = 0;
+                }
             }
         }
-        if (rb0 + RB < nrec) __syncthreads();  // the next batch reuses the map and the bitmaps
+        if (more) {
+            if (dma && (uint32_t)wave * 64 < nRBn) dma_row(ncols, wave * 64, rb0 + RB, nRBn);  // the record ends this wave reads
+            __syncthreads();  // the next batch reuses the bitmaps (and, fetched by all waves, the map)
+        }
     }
     if (deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
     // (behind the barrier that follows the last batch's columns) every column must have come out
@@ -2835,17 +2867,16 @@ hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream) {
     if (P.ntiles == 0) return hipSuccess;
     if (!P.cellmap || !P.map_stride) return hipSuccess;  // no map at all: the full write kernel does every tile
     // (schemas with time or binary32 columns take the instance that converts them on the spot)
-    const void *fn = P.special_cols ? (const void *)emit_kernel<true> : (const void *)emit_kernel<false>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const bool many = (P.L.RB & 63u) == 0;  // (the layout for inputs of short records)
+    void (*const fn)(const TileParams) = P.special_cols ? (many ? emit_kernel<true, true> : emit_kernel<true, false>)
+                                                        : (many ? emit_kernel<false, true> : emit_kernel<false, false>);
+    hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     uint32_t lds = P.L.total;
 #ifdef MDC_ABLATE
     if (const char *e = getenv("MDC_DEBUG_LDS")) lds = (uint32_t)atoi(e);  // occupancy experiments
 #endif
-    if (P.special_cols)
-        hipLaunchKernelGGL(emit_kernel<true>, dim3(P.ntiles), dim3(BLOCK), lds, stream, P);
-    else
-        hipLaunchKernelGGL(emit_kernel<false>, dim3(P.ntiles), dim3(BLOCK), lds, stream, P);
+    hipLaunchKernelGGL(fn, dim3(P.ntiles), dim3(BLOCK), lds, stream, P);
     return hipGetLastError();
 }
 
