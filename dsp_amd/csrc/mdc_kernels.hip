@@ -1685,7 +1685,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     for (uint32_t rb0 = 0; rb0 < nrec; rb0 += RB) {
         const uint32_t RBn = (nrec - rb0 < RB) ? nrec - rb0 : RB;
         for (uint32_t i = tid; i < (RB * npat + 1) / 2; i += BLOCK) evt[i] = NONE;
-        if (WRITE || csv)  // (the sizing pass of tagged input keeps the tag template there)
+        if (WRITE)  // (the sizing pass keeps the tag template there; its delimited walk stores whole words)
             for (uint32_t i = tid; i < RB * W; i += BLOCK) {
                 vmask[i] = 0;
                 fmask[i] = 0;
@@ -1786,40 +1786,6 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         STAMP(3);  // events
 
         // ---- E. cells: descriptor, length, typed value
-        if (fastcsv) {
-            // one lane per (field, record): field c lies between the record's separators c-1 and c
-            const uint32_t nitems = ncols * RBn;
-            const uint32_t magic = 0xFFFFFFFFu / RBn + 1;  // i / RBn == umulhi(i, magic) for i < 2^15, RBn <= 256
-            for (uint32_t i = tid; i < nitems; i += BLOCK) {
-                const uint32_t c = RBn == 1 ? i : __umulhi(i, magic);
-                const uint32_t r = i - c * RBn;
-                if (r == 0 && rb0 == 0 && slow0) continue;
-                const uint32_t rs = recend[r] + 1, re = recend[r + 1];
-                const uint32_t first = e0[r], nsep = e0[r + 1] - first;
-                uint32_t fs = re, fl = 0;
-                if (c <= nsep) {
-                    fs = c ? (uint32_t)evpos[first + c - 1] + seplen : rs;
-                    fl = (c < nsep ? (uint32_t)evpos[first + c] : re) - fs;
-                    if (H->bdelspace) {
-                        // deletelchr then deleterchr with its "pos != 0" test
-                        // (public/_public.cpp:24-31, :52-59)
-                        while (fl && sdata[fs] == ' ') {
-                            ++fs;
-                            --fl;
-                        }
-                        if (fl) {
-                            uint32_t lastp = fl - 1;
-                            while (sdata[fs + lastp] == ' ') --lastp;  // fs itself is not a blank
-                            if (lastp != 0) fl = lastp + 1;
-                        }
-                    }
-                    const int cl = cols[c].collen;
-                    if (cl > 0 && (uint32_t)cl < fl) fl = (uint32_t)cl;
-                    atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
-                }
-                desc[c * RB + r] = desc_pack(fs, fl, LVL_CHAR);
-            }
-        }
         if (csv && (!fastcsv || (slow0 && rb0 == 0))) {
             // greedy left-to-right separator search, one lane per record (ccmdstr::splittocmd)
             if ((uint32_t)tid < (fastcsv ? 1u : RBn)) {
@@ -1881,7 +1847,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 }
             }
         }
-        if (csv) __syncthreads();
+        if (csv && (!fastcsv || (slow0 && rb0 == 0))) __syncthreads();
         STAMP(4);  // delimited descriptors
 
         const bool nulcut = carry && !csv;
@@ -1949,7 +1915,63 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 len = (uint32_t)l;
             }
         };
-        if (!WRITE) {
+        if (!WRITE && fastcsv) {
+            // Delimited input whose separators were collected: one lane per (field, record).  Field c
+            // lies between the record's separators c-1 and c; a field is text, so its length is all the
+            // sizing pass needs (no descriptor in LDS, no second loop).  Only a first record that starts
+            // in the look-behind was walked by one lane, which left its descriptors behind.
+            const uint32_t nitems = ncols * RBn;
+            const uint32_t magic = 0xFFFFFFFFu / RBn + 1;  // i / RBn == umulhi(i, magic) for i < 2^15, RBn <= 256
+            for (uint32_t i0 = (uint32_t)wave * 64; i0 < nitems && !SKIP(2); i0 += BLOCK) {
+                const uint32_t i = i0 + lane;
+                const bool act = i < nitems;
+                const uint32_t c = !act ? ncols - 1 : RBn == 1 ? i : __umulhi(i, magic);
+                const uint32_t r = act ? i - c * RBn : 0;
+                uint32_t fs = 0, fl = 0;
+                bool found = false;
+                if (act && r == 0 && rb0 == 0 && slow0) {
+                    uint32_t lvl;
+                    fetch_cell(c, 0, fs, fl, lvl, found);
+                } else if (act) {
+                    const uint32_t rs = recend[r] + 1, re = recend[r + 1];
+                    const uint32_t first = e0[r], nsep = e0[r + 1] - first;
+                    fs = re;
+                    if (c <= nsep) {
+                        fs = c ? (uint32_t)evpos[first + c - 1] + seplen : rs;
+                        fl = (c < nsep ? (uint32_t)evpos[first + c] : re) - fs;
+                        if (H->bdelspace) {
+                            // deletelchr then deleterchr with its "pos != 0" test
+                            // (public/_public.cpp:24-31, :52-59)
+                            while (fl && sdata[fs] == ' ') {
+                                ++fs;
+                                --fl;
+                            }
+                            if (fl) {
+                                uint32_t lastp = fl - 1;
+                                while (sdata[fs + lastp] == ' ') --lastp;  // fs itself is not a blank
+                                if (lastp != 0) fl = lastp + 1;
+                            }
+                        }
+                        const int cl = cols[c].collen;
+                        if (cl > 0 && (uint32_t)cl < fl) fl = (uint32_t)cl;
+                        found = true;
+                    }
+                }
+                if (mapping && act) {
+                    if (fl < MAP_MAXLEN)
+                        P.cellmap[(uint64_t)c * P.map_cap + slot + rb0 + r] = map_pack(fs, fl, LVL_CHAR, found);
+                    else
+                        ms[MS_NOMAP] = 1;
+                }
+                const uint32_t incl = wave_incl_scan(fl);
+                // this column's run in the wave: lanes [first, last]
+                const uint32_t cstart = c * RBn, cend = cstart + RBn - 1;
+                const uint32_t first = cstart > i0 ? cstart - i0 : 0;
+                const uint32_t last = cend - i0 < 63 ? cend - i0 : 63;
+                const uint32_t before = __shfl(incl, first ? first - 1 : 0, 64);
+                if (act && (uint32_t)lane == last) atomicAdd(&tiletot[c], incl - (first ? before : 0));
+            }
+        } else if (!WRITE) {
             // Sizing needs the cells' lengths and the columns' totals only, no order among the
             // cells: one lane per (column, record), all lanes busy.  A wave's lanes hold
             // consecutive records of (usually) one or two columns; the last lane of each column's
