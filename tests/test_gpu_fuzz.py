@@ -141,10 +141,11 @@ def random_lines(rng, nlines, sep: bytes, nfields, regular):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MDC_FUZZ_SEEDS", "24"))))
 def test_random_delimited(port, seed, utc):
-    """Random separators (one byte: the parallel split; more: the serial walk), field counts, clips,
-    conversions and trimming over lines from all well-formed to all odd."""
+    """Random separators (up to four bytes: the parallel split, unless two matches overlap in a tile, as
+    they do for "aa" and "b b" in these lines; longer: the walk), field counts, clips, conversions and
+    trimming over lines from all well-formed to all odd."""
     rng = random.Random(7000 + seed)
-    sep = rng.choice([",", ",", ";", "|", " ", "\t", "~!~", "::", "ab"])
+    sep = rng.choice([",", ",", ";", "|", " ", "\t", "~!~", "::", "ab", "aa", "b b", "-.-.", "0.0.0"])
     nfields = rng.choice([1, 2, 3, 6, 10, 10, 17, 40])
     ilen = [rng.choice([0, 0, 0, 1, 3, 8, 9, 16, 17, 30]) for _ in range(nfields)]
     typed = [rng.choice([0, 0, 1, 2, 3, 4, 5, 5, 6, 7, 8]) for _ in range(nfields)]
