@@ -38,7 +38,7 @@ EXPORTS = [
     "mdc_parser_create_xml", "mdc_parser_create_csv", "mdc_parser_destroy",
     "mdc_parse_device", "mdc_parse_host", "mdc_parse_file", "mdc_parse_device_noalloc", "mdc_parser_last_timing",
     "mdc_parse_xml_buffer", "mdc_parse_xml_file", "mdc_parse_csv_buffer",
-    "mdc_stream_open", "mdc_stream_next", "mdc_stream_bytes", "mdc_stream_close",
+    "mdc_stream_open", "mdc_stream_next", "mdc_stream_bytes", "mdc_stream_close", "mdc_stream_release_pinned",
     "mdc_batch_rows", "mdc_batch_ncols", "mdc_batch_words_per_row",
     "mdc_batch_device_column", "mdc_batch_device_values", "mdc_batch_device_masks", "mdc_batch_device_recoff",
     "mdc_batch_host_column", "mdc_batch_host_values", "mdc_batch_host_masks", "mdc_batch_host_recoff",
@@ -133,6 +133,8 @@ def lib():
         L.mdc_stream_bytes.restype = ctypes.c_uint64
         L.mdc_stream_close.argtypes = [vp]
         L.mdc_stream_close.restype = None
+        L.mdc_stream_release_pinned.argtypes = []
+        L.mdc_stream_release_pinned.restype = None
         L.mdc_batch_rows.restype = i64
         L.mdc_batch_rows.argtypes = [vp]
         L.mdc_batch_ncols.argtypes = [vp]

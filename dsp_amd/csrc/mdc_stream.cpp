@@ -9,8 +9,8 @@
 // time: open, read, parse) for inputs that tools/gzipfiles.cpp:59 has compressed.  Built on the
 // public entry points of mdc_parse.h plus the HIP runtime.  Kernel launches, copies and stream
 // waits are made on the thread that calls mdc_stream_next; the worker threads bind the parser's
-// device (hipSetDevice) only to allocate and free their pinned buffers (hipHostMalloc,
-// hipHostFree) and touch no stream.
+// device (hipSetDevice) only to allocate their pinned buffers (hipHostMalloc; kept for the next
+// stream when this one is closed) and touch no stream.
 #include <hip/hip_runtime.h>
 #include <zlib.h>
 
@@ -42,17 +42,63 @@ struct Slot {
     bool uploading = false;
 };
 
+// Pinning host memory costs about as much as reading a file into it, so the buffers of a closed
+// stream are kept (up to POOL_MAX_BYTES per process) for the next one: an ingest opens a stream per
+// directory scan (tools/xmltodb.cpp:147-218 runs that loop every few seconds).
+struct PinnedBuf {
+    uint8_t *p;
+    size_t cap;
+};
+std::mutex g_pool_mu;
+std::vector<PinnedBuf> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t POOL_MAX_BYTES = (size_t)2 << 30;
+
+// a pinned buffer of at least `want` bytes: the smallest kept one that fits, else a new one
+bool pinned_get(size_t want, PinnedBuf &out) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t best = g_pool.size();
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i].cap >= want && (best == g_pool.size() || g_pool[i].cap < g_pool[best].cap)) best = i;
+        if (best < g_pool.size() && g_pool[best].cap <= 2 * want + ((size_t)8 << 20)) {
+            out = g_pool[best];
+            g_pool_bytes -= out.cap;
+            g_pool.erase(g_pool.begin() + (long)best);
+            return true;
+        }
+    }
+    const size_t cap = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    uint8_t *q = nullptr;
+    if (hipHostMalloc((void **)&q, cap, hipHostMallocPortable) != hipSuccess) return false;
+    out.p = q;
+    out.cap = cap;
+    return true;
+}
+
+void pinned_put(uint8_t *p, size_t cap) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_pool_bytes + cap <= POOL_MAX_BYTES) {
+            g_pool.push_back({p, cap});
+            g_pool_bytes += cap;
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
 // grows a pinned buffer, keeping its first `keep` bytes
 bool pinned_reserve(Slot &s, size_t want, size_t keep) {
     if (want <= s.cap) return true;
-    size_t cap = s.cap ? s.cap : (size_t)1 << 20;
-    while (cap < want) cap *= 2;
-    uint8_t *q = nullptr;
-    if (hipHostMalloc((void **)&q, cap, hipHostMallocDefault) != hipSuccess) return false;
-    if (keep) memcpy(q, s.h, keep);
-    if (s.h) (void)hipHostFree(s.h);
-    s.h = q;
-    s.cap = cap;
+    if (s.cap && want < s.cap + s.cap / 2) want = s.cap + s.cap / 2;  // (a file that grows while it is read)
+    PinnedBuf b;
+    if (!pinned_get(want, b)) return false;
+    if (keep) memcpy(b.p, s.h, keep);
+    pinned_put(s.h, s.cap);
+    s.h = b.p;
+    s.cap = b.cap;
     return true;
 }
 
@@ -318,7 +364,16 @@ extern "C" void mdc_stream_close(mdc_stream *s) {
         if (e) (void)hipEventDestroy(e);
     for (auto &b : s->dbuf)
         if (b) (void)mdc_device_free(s->device, b);
-    for (auto &slot : s->slots)
-        if (slot.h) (void)hipHostFree(slot.h);
+    for (auto &slot : s->slots) pinned_put(slot.h, slot.cap);
     delete s;
+}
+
+extern "C" void mdc_stream_release_pinned(void) {
+    std::vector<PinnedBuf> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        drop.swap(g_pool);
+        g_pool_bytes = 0;
+    }
+    for (auto &b : drop) (void)hipHostFree(b.p);
 }

@@ -214,6 +214,10 @@ int mdc_stream_next(mdc_stream *s, mdc_batch **out, int *index);
 /* uncompressed bytes handed to the parser so far */
 uint64_t mdc_stream_bytes(const mdc_stream *s);
 void mdc_stream_close(mdc_stream *s);
+/* A closed stream's pinned host buffers are kept for the next stream of the process (at most 2 GiB:
+ * pinning memory costs about as much as reading a file into it, and the ingest opens a stream per
+ * directory scan, tools/xmltodb.cpp:147-218).  This gives them back to the system. */
+void mdc_stream_release_pinned(void);
 
 /* ---- batches ------------------------------------------------------------------------ */
 
