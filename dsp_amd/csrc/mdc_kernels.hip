@@ -1432,6 +1432,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     uint32_t *tiletot = coltot + (ncols + 1);          // totals of the batches done so far
     for (uint32_t c = tid; c < ncols + 1; c += BLOCK) tiletot[c] = 0;
     STAMP(0);  // loads
+    if (!WRITE && SKIP(8)) return;  // (diagnostic builds: the kernel up to here)
 
     // searches the staged chunks [lo, hi) for record terminators; keeps the last one
     auto search_terminators = [&](int lo_li, int hi_li) {
@@ -1680,6 +1681,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         }
     }
     STAMP(1);  // classify + rank scan
+    if (!WRITE && SKIP(4)) return;  // (diagnostic builds: the kernel up to here)
 
     // ---- batches of RB records
     for (uint32_t rb0 = 0; rb0 < nrec; rb0 += RB) {

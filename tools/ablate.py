@@ -1,5 +1,5 @@
 """Diagnostic: kernel time with phases switched off (libmdc_parse_ablate.so, MDC_DEBUG_SKIP bits:
-1 = tag events, 2 = cells, 16 = emit kernel without its columns, 32 = emit kernel without the columns' stores).  Outputs are wrong by construction; only the times matter."""
+1 = tag events, 2 = cells, 4 = sizing pass ends behind classification and scan, 8 = behind its loads, 16 = emit kernel without its columns, 32 = emit kernel without the columns' stores).  Outputs are wrong by construction; only the times matter."""
 import os
 import subprocess
 import sys
