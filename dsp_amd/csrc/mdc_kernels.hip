@@ -2253,16 +2253,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     }
     const uint32_t RB = L.RB;
     const uint32_t RBs = P.map_stride < RB ? P.map_stride : RB;  // records of the first batch, at most
-    const uint32_t nwords = (ncols + 1) * RBs;
-    const uint32_t magic_s = 0xFFFFFFFFu / RBs + 1;  // i / RBs == umulhi(i, magic_s) for i < 2^15 (RBs >= 2)
-    constexpr int MAPREG = 8;
-    uint32_t mv[MAPREG];
+    // The first batch's map words: every wave fetches the rows it reads itself (its columns' rows, two
+    // words a lane, and its 64 record ends), which needs no division to find a word's place.  Three
+    // columns a wave are fetched here, the rows of wider schemas behind the first wait.
+    constexpr int MAPCOLS = 3;
+    uint32_t mv[2 * MAPCOLS + 1];
+    const uint32_t r_lo = (uint32_t)lane < RBs ? lane : RBs - 1, r_hi = (uint32_t)lane + 64 < RBs ? lane + 64 : RBs - 1;
+    const uint32_t *const mbase = P.cellmap + slot;
 #pragma unroll
-    for (int k = 0; k < MAPREG; ++k) {
-        const uint32_t i0 = (uint32_t)k * BLOCK + tid;
-        const uint32_t i = i0 < nwords ? i0 : 0;
-        const uint32_t c = RBs == 1 ? i : __umulhi(i, magic_s);
-        mv[k] = P.cellmap[(uint64_t)c * P.map_cap + slot + (i - c * RBs)];
+    for (int j = 0; j < MAPCOLS; ++j) {
+        const uint32_t c0 = (uint32_t)wave + (uint32_t)j * (BLOCK / 64);
+        const uint32_t c = c0 < ncols ? c0 : 0;
+        mv[2 * j] = mbase[(uint64_t)c * P.map_cap + r_lo];
+        mv[2 * j + 1] = mbase[(uint64_t)c * P.map_cap + r_hi];
+    }
+    {
+        const uint32_t r = (uint32_t)tid < RBs ? tid : RBs - 1;  // (RBs <= 128: waves 0 and 1 hold the record ends)
+        mv[2 * MAPCOLS] = mbase[(uint64_t)ncols * P.map_cap + r];
     }
     // of the schema only the header, the columns and the powers of ten (the tag table stays out)
     const uint32_t sch_head = (uint32_t)sizeof(SchemaHdr) + ((ncols * (uint32_t)sizeof(DevCol) + 15) & ~15u);
@@ -2311,15 +2318,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     // (rare) the first record starts in front of the first look-behind window
     for (int j = s0_li / CHUNK + tid; j < (ts_li - LB_FIRST) / CHUNK; j += BLOCK) ((uint4 *)sdata)[j] = load_chunk(j);
 #pragma unroll
-    for (int k = 0; k < MAPREG; ++k) {
-        const uint32_t i = (uint32_t)k * BLOCK + tid;
-        const uint32_t c = RBs == 1 ? i : __umulhi(i, magic_s);
-        if (i < nwords) mapl[c * RB + (i - c * RBs)] = mv[k];
+    for (int j = 0; j < MAPCOLS; ++j) {
+        const uint32_t c = (uint32_t)wave + (uint32_t)j * (BLOCK / 64);
+        if (c < ncols) {
+            if ((uint32_t)lane < RBs) mapl[c * RB + lane] = mv[2 * j];
+            if ((uint32_t)lane + 64 < RBs) mapl[c * RB + lane + 64] = mv[2 * j + 1];
+        }
     }
-    for (uint32_t i = MAPREG * BLOCK + tid; i < nwords; i += BLOCK) {  // schemas with many columns
-        const uint32_t c = RBs == 1 ? i : __umulhi(i, magic_s);
-        mapl[c * RB + (i - c * RBs)] = P.cellmap[(uint64_t)c * P.map_cap + slot + (i - c * RBs)];
-    }
+    if ((uint32_t)tid < RBs) mapl[ncols * RB + tid] = mv[2 * MAPCOLS];
+    for (uint32_t c = (uint32_t)wave + MAPCOLS * (BLOCK / 64); c < ncols; c += BLOCK / 64)  // schemas with many columns
+        for (uint32_t r = lane; r < RBs; r += 64) mapl[c * RB + r] = mbase[(uint64_t)c * P.map_cap + r];
     // the map words of a later batch
     auto load_map = [&](uint32_t rb0, uint32_t RBn) {
         for (uint32_t c = wave; c <= ncols; c += BLOCK / 64) {
