@@ -2277,17 +2277,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     uint32_t *sized = tiletot + (ncols + 1);  // the sizing pass's bytes per column of this tile
     ColOut *colout = (ColOut *)(smem + L.colout);
     const uint64_t *tb = P.tile_base + (uint64_t)tile * (ncols + 1);
-    {
-        // (a thread beyond a table's end copies entry 0 once more: the same bytes to the same
-        // place, and no branch around the load)
+    if (wave == 0) {
+        // One wave fetches the block's tables, as the last loads before the wait that all loads share.
+        // (A lane beyond a table's end copies entry 0 once more: the same bytes to the same place, and no
+        // branch around a load.)
         const uint4 *g = (const uint4 *)P.schema;
         uint4 *s = (uint4 *)(smem + L.schema);
         const uint64_t *gp = (const uint64_t *)(P.schema + P.p10_off);
         uint64_t *sp = (uint64_t *)(smem + L.schema + sch_head);
         const uint32_t sch16 = sch_head / 16;
-        const uint32_t si = (uint32_t)tid < sch16 ? tid : 0;
-        const uint32_t pi = tid < P10_TABLE_DOUBLES ? tid : 0;
-        const uint32_t cc = (uint32_t)tid < ncols ? tid : 0;
+        const uint32_t si = (uint32_t)lane < sch16 ? lane : 0;
+        const uint32_t pi = lane < P10_TABLE_DOUBLES ? lane : 0;
+        const uint32_t cc = (uint32_t)lane < ncols ? lane : 0;
         const uint4 sv = g[si];
         const uint64_t pv = gp[pi];
         ColOut o;
@@ -2297,11 +2298,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         o.base = tb[cc];
         const uint32_t szv = P.tile_counts[(uint64_t)tile * (ncols + 1) + cc];
         s[si] = sv;
-        for (uint32_t i = tid + BLOCK; i < sch16; i += BLOCK) s[i] = g[i];
+        for (uint32_t i = lane + 64; i < sch16; i += 64) s[i] = g[i];
         sp[pi] = pv;
         tiletot[cc] = 0;
         sized[cc] = szv;
         colout[cc] = o;
+        for (uint32_t c = lane + 64; c < ncols; c += 64) {  // schemas with more than 64 columns
+            ColOut o2;
+            o2.off = P.off[c];
+            o2.bytes = P.bytes[c];
+            o2.val = P.val[c];
+            o2.base = tb[c];
+            tiletot[c] = 0;
+            sized[c] = P.tile_counts[(uint64_t)tile * (ncols + 1) + c];
+            colout[c] = o2;
+        }
     }
     const uint32_t hslot = __builtin_amdgcn_readfirstlane(hslot_v);
     const uint32_t hw = __builtin_amdgcn_readfirstlane(hw_v);
