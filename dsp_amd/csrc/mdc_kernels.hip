@@ -2146,13 +2146,13 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
             }
         }
         if (rb0 + RB >= nrec) break;  // (the totals below are read behind the barrier that follows the cells)
-        __syncthreads();
-        STAMP(9);  // row outputs
+        // (entry 0 is read by nobody in this phase: the row outputs read entries 1 to RBn)
         if (tid == 0) {
             recend[0] = recend[RBn];
             if (tmode) e0t[0] = e0t[RBn];
         }
         __syncthreads();
+        STAMP(9);  // row outputs
     }
 
     if (WRITE) {
