@@ -15,6 +15,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <ctime>
@@ -83,9 +84,14 @@ static const size_t REPORT_TOTALS = 32;
 static_assert(NOALLOC_SCRATCH_BYTES == MDC_NOALLOC_SCRATCH_BYTES, "the header states the size of the static scratch array");
 static const size_t STATUS_BYTES = (REPORT_TOTALS + MAX_COLS + 8) * 8;
 
+constexpr int UPLOAD_THREADS = 4;  // host threads staging a pageable buffer (mdc_parse_host)
+
 struct Device {
     int id = -1;
     hipStream_t stream = nullptr;
+    hipStream_t up_stream[UPLOAD_THREADS] = {};     // created on the first large host buffer
+    hipEvent_t up_event[2 * UPLOAD_THREADS] = {};
+    std::mutex up_mu;  // one staged upload at a time per device (they would share the link anyway)
     std::mutex mu;
     std::multimap<size_t, void *> free_blocks;
     std::map<void *, size_t> live;
@@ -1043,6 +1049,76 @@ extern "C" int mdc_parse_device_noalloc(mdc_parser *p, const void *d_data, size_
     return parse_impl(p, d_data, n, o, nullptr, rows, col_bytes);
 }
 
+extern "C" int mdc_internal_pinned_get(size_t want, uint8_t **p, size_t *cap);
+extern "C" void mdc_internal_pinned_put(uint8_t *p, size_t cap);
+
+// A host buffer into device memory.  The runtime takes a pageable source through one staging copy
+// of its own (about 28 GB/s here); a large buffer is instead cut into 8 MiB pieces that a few host
+// threads copy into pinned buffers (two a thread, kept from call to call) and upload on a copy stream
+// each, the copy of one piece beside the upload of the one before.
+static hipError_t upload_host(Device *d, void *dbuf, const void *h_data, size_t n) {
+    constexpr size_t PIECE = (size_t)8 << 20;
+    const size_t npieces = (n + PIECE - 1) / PIECE;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t T = std::min<size_t>({(size_t)UPLOAD_THREADS, npieces / 2, hw ? hw : 1});
+    if (T >= 2) {  // a source that is pinned already goes up as it is
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, h_data) == hipSuccess) {
+            if (at.type == hipMemoryTypeHost) T = 1;
+        } else {
+            (void)hipGetLastError();  // (plain pageable memory is unknown to the runtime: not an error here)
+        }
+    }
+    if (T < 2) {
+        hipError_t e = hipMemcpyAsync(dbuf, h_data, n, hipMemcpyHostToDevice, d->stream);
+        return e == hipSuccess ? hipStreamSynchronize(d->stream) : e;
+    }
+    std::lock_guard<std::mutex> one(d->up_mu);
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        for (int t = 0; t < UPLOAD_THREADS; ++t) {
+            if (!d->up_stream[t]) {
+                hipError_t e = hipStreamCreateWithFlags(&d->up_stream[t], hipStreamNonBlocking);
+                if (e != hipSuccess) return e;
+            }
+            for (int b = 0; b < 2; ++b)
+                if (!d->up_event[2 * t + b]) {
+                    hipError_t e = hipEventCreateWithFlags(&d->up_event[2 * t + b], hipEventDisableTiming);
+                    if (e != hipSuccess) return e;
+                }
+        }
+    }
+    hipError_t errs[UPLOAD_THREADS];
+    auto work = [&](size_t t) {
+        hipError_t e = hipSetDevice(d->id);
+        uint8_t *buf[2] = {nullptr, nullptr};
+        size_t cap[2] = {0, 0};
+        for (int b = 0; b < 2 && e == hipSuccess; ++b)
+            if (!mdc_internal_pinned_get(PIECE, &buf[b], &cap[b])) e = hipErrorOutOfMemory;
+        size_t j = 0;
+        for (size_t k = t; k < npieces && e == hipSuccess; k += T, ++j) {
+            const int b = (int)(j & 1);
+            if (j >= 2) e = hipEventSynchronize(d->up_event[2 * t + b]);  // the piece this buffer held is up
+            if (e != hipSuccess) break;
+            const size_t off = k * PIECE, len = n - off < PIECE ? n - off : PIECE;
+            memcpy(buf[b], (const uint8_t *)h_data + off, len);
+            e = hipMemcpyAsync((uint8_t *)dbuf + off, buf[b], len, hipMemcpyHostToDevice, d->up_stream[t]);
+            if (e == hipSuccess) e = hipEventRecord(d->up_event[2 * t + b], d->up_stream[t]);
+        }
+        const hipError_t e2 = hipStreamSynchronize(d->up_stream[t]);  // (also before the buffers go back)
+        for (int b = 0; b < 2; ++b)
+            if (buf[b]) mdc_internal_pinned_put(buf[b], cap[b]);
+        errs[t] = e != hipSuccess ? e : e2;
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    for (size_t t = 0; t < T; ++t)
+        if (errs[t] != hipSuccess) return errs[t];
+    return hipSuccess;
+}
+
 extern "C" int mdc_parse_host(mdc_parser *p, const void *h_data, size_t n, mdc_batch **out) {
     if (!p || !out) return fail(MDC_ERR_ARG, "NULL argument");
     *out = nullptr;
@@ -1053,8 +1129,7 @@ extern "C" int mdc_parse_host(mdc_parser *p, const void *h_data, size_t n, mdc_b
     int rc = dev_alloc(d, n + 64, &dbuf);
     if (rc) return rc;
     if (n) {
-        hipError_t e = hipMemcpyAsync(dbuf, h_data, n, hipMemcpyHostToDevice, d->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        const hipError_t e = upload_host(d, dbuf, h_data, n);
         if (e != hipSuccess) {
             dev_free(d, dbuf);
             return fail(MDC_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));

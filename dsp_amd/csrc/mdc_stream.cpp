@@ -368,6 +368,16 @@ extern "C" void mdc_stream_close(mdc_stream *s) {
     delete s;
 }
 
+// (for mdc_parse_host, which stages a pageable buffer through the same kept pinned buffers)
+extern "C" int mdc_internal_pinned_get(size_t want, uint8_t **p, size_t *cap) {
+    PinnedBuf b;
+    if (!pinned_get(want, b)) return 0;
+    *p = b.p;
+    *cap = b.cap;
+    return 1;
+}
+extern "C" void mdc_internal_pinned_put(uint8_t *p, size_t cap) { pinned_put(p, cap); }
+
 extern "C" void mdc_stream_release_pinned(void) {
     std::vector<PinnedBuf> drop;
     {

@@ -145,7 +145,9 @@ void mdc_parser_destroy(mdc_parser *p);
  * must be 16-byte aligned and stay valid until the call returns (the call synchronises the
  * parser's stream before returning). */
 int mdc_parse_device(mdc_parser *p, const void *d_data, size_t n, mdc_batch **out);
-/* Parse n bytes of host memory (copied to the device through a pinned staging buffer). */
+/* Parse n bytes of host memory.  A buffer of 32 MiB or more that is not pinned is copied in 8 MiB
+ * pieces by up to four host threads through pinned buffers (the ones file streams keep, see
+ * mdc_stream_release_pinned) and uploaded piece by piece; a pinned or small one goes up in one copy. */
 int mdc_parse_host(mdc_parser *p, const void *h_data, size_t n, mdc_batch **out);
 /* Parse a whole file; MDC_FILE_OPEN_FAILED (5) when it cannot be opened. */
 int mdc_parse_file(mdc_parser *p, const char *path, mdc_batch **out);
