@@ -390,6 +390,22 @@ def test_wide_schemas_with_and_without_room_for_the_template(port, ncols):
     assert_batches_equal(got, port.parse_xml(data, cols), "ncols=%d" % ncols)
 
 
+@pytest.mark.parametrize("nbytes", [(32 << 20) - 5, (32 << 20) + 1, (56 << 20) + 4097, 100 << 20])
+def test_large_host_buffers_go_up_in_pieces(nbytes):
+    # a pageable buffer of 32 MiB or more is staged in 8 MiB pieces by several host threads: the parse
+    # must equal the parse of the same bytes put into device memory with one copy
+    data, n = gen.mind_xml(nbytes=nbytes)
+    p = capi.Parser.xml(schema.ZHOBTMIND)
+    d = capi.DeviceBuffer(data)
+    want = p.parse_device(d.ptr, d.n).to_host()
+    for _ in range(2):  # (the second call reuses the pinned buffers the first one left)
+        got = p.parse_host(data).to_host()
+        assert got.rows == n
+        assert_batches_equal(got, want, f"host buffer of {nbytes} bytes")
+    d.free()
+    p.close()
+
+
 def test_many_tiles(port):
     data, n = gen.mind_xml(nbytes=48 << 20)
     p = capi.Parser.xml(schema.ZHOBTMIND)
