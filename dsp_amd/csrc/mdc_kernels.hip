@@ -1444,7 +1444,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
                 nl &= nl - 1;
                 const int p = j * CHUNK + b;
                 bool t;
-                if (p - (int)H->endbz_len >= lo_li) {
+                if (p >= 8 && p - (int)H->endbz_len >= lo_li) {  // (is_term reads the eight bytes in front of p)
                     t = is_term(sdata, H, base_pos, p);
                 } else {  // endbz bytes below the staged region are read from global memory
                     const int el = (int)H->endbz_len;

@@ -235,6 +235,23 @@ def test_delimited_lines_longer_than_the_look_behind(port, sep, bdel):
     p.close()
 
 
+@pytest.mark.parametrize("endbz", ["##", "<endl/>", ""])
+def test_record_that_starts_in_the_first_bytes_of_the_look_behind(port, endbz):
+    # The first record of the second tile starts d bytes behind the place the look-behind reaches back
+    # to (1,536 bytes in front of the tile), so the terminator in front of it stands in the first bytes
+    # of the staged image, where the check of the end mark must not read in front of the image.
+    e = endbz.encode()
+    for d in range(0, 14):
+        start = 16384 - 1536 + d                      # where the second record starts
+        a = b"<a>1</a><ab>" + b"p" * (start - 12 - 5 - len(e) - 1) + b"</ab>" + e + b"\n"
+        assert len(a) == start
+        b = b"<a>22</a><ab>" + b"q" * 1600 + b"</ab><b>7.5</b>" + e + b"\n"    # ends in the second tile
+        rest = b"".join(b"<a>%d</a><ab>v%d</ab><b>%d.25</b>" % (i, i, i) + e + b"\n" for i in range(400))
+        data = a + b + rest
+        got = gpu_xml(data, cases.SMALL, endbz=endbz)
+        assert_batches_equal(got, port.parse_xml(data, cases.SMALL, endbz=endbz), f"endbz {endbz!r}, d {d}")
+
+
 def test_long_cells_bypass_staging(port):
     # cells larger than the LDS staging area take the direct store path
     recs = [b"<ab>" + bytes([65 + (i % 26)]) * 3000 + b"</ab><a>k%d</a><endl/>\n" % i for i in range(30)]
