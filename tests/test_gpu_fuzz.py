@@ -13,6 +13,9 @@ from dsp_amd import capi, schema
 from dsp_amd.schema import Col
 from util import assert_batches_equal
 
+# seeds of the random tests: 24 per run; MDC_FUZZ_SEEDS more of them, from MDC_FUZZ_FIRST on, for a longer hunt
+SEEDS = range(int(os.environ.get("MDC_FUZZ_FIRST", "0")), int(os.environ.get("MDC_FUZZ_FIRST", "0")) + int(os.environ.get("MDC_FUZZ_SEEDS", "24")))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -54,7 +57,7 @@ def resolve(cols, typed):
     return [d[i] if t < 0 else t for i, t in enumerate(typed)]
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MDC_FUZZ_SEEDS", "24"))))  # (more seeds for a longer hunt)
+@pytest.mark.parametrize("seed", SEEDS)  # (more seeds for a longer hunt)
 def test_random_schema(port, seed, utc):
     rng = random.Random(1000 + seed)
     cols, typed = random_schema(rng)
@@ -139,7 +142,7 @@ def random_lines(rng, nlines, sep: bytes, nfields, regular):
     return bytes(out)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MDC_FUZZ_SEEDS", "24"))))
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_delimited(port, seed, utc):
     """Random separators (up to four bytes: the parallel split, unless two matches overlap in a tile, as
     they do for "aa" and "b b" in these lines; longer: the walk), field counts, clips, conversions and
@@ -223,7 +226,7 @@ def test_plain_binary32_cells(port):
     assert int(np.count_nonzero(exp.valid[:, 0] & 1)) > 29000
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MDC_FUZZ_SEEDS", "24"))))
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_long_records(port, seed, utc):
     """Records of a few hundred bytes to some hundred KiB (every one spans tiles, the larger look-behind
     levels and the long-record kernel come into play), long cells with tag-like text, NUL bytes and
@@ -262,7 +265,7 @@ def test_random_long_records(port, seed, utc):
         p.close()
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MDC_FUZZ_SEEDS", "24"))))
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_format(port, seed):
     """The writer side on random columns: 1 to 40 fields, names of 1 to 40 bytes, values from empty to
     a few thousand bytes with NUL bytes now and then, cuts or none, files of any number of rows."""
