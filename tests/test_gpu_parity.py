@@ -110,6 +110,47 @@ def test_short_records_many_batches(port):
     assert_batches_equal(got, exp, "short records")
 
 
+@pytest.mark.parametrize("reclen", [63, 64, 65, 126, 127, 128, 129, 130, 143, 144, 145, 146, 147, 148, 170, 171, 172, 255, 256, 257])
+def test_records_per_tile_around_the_batch_sizes(port, reclen):
+    # records of one length each: 16 KiB tiles then hold 64, 112, 113, 127 to 130 ... records, the counts
+    # at which a tile needs one batch more (batches of 112 records, of 128 for inputs of short records)
+    fixed = len(b"<a>12345</a><ab></ab><b>-12.25</b><endl/>\n")
+    recs = [b"<a>%05d</a><ab>" % (i % 100000) + bytes([97 + i % 26]) * (reclen - fixed) + b"</ab><b>-12.25</b><endl/>\n"
+            for i in range(2600)]
+    assert len(recs[0]) == reclen
+    data = b"".join(recs)
+    p = capi.Parser.xml(cases.SMALL, typed=[schema.T_I64, schema.T_NONE, schema.T_F64])
+    exp = port.parse_xml(data, cases.SMALL, typed=[schema.T_I64, schema.T_NONE, schema.T_F64])
+    for _ in range(2):  # (the second parse sizes the cell map by the first one's records per tile)
+        got = p.parse_host(data).to_host()
+        assert_batches_equal(got, exp, f"records of {reclen} bytes")
+    p.close()
+    # the same lines as delimited input
+    lines = b"".join(b"%05d,%s,-12.25\n" % (i % 100000, bytes([97 + i % 26]) * (reclen - 14)) for i in range(2600))
+    q = capi.Parser.csv(",", 3, typed=[schema.T_I64, schema.T_NONE, schema.T_F64])
+    expc = port.parse_csv(lines, ",", 3, typed=[schema.T_I64, schema.T_NONE, schema.T_F64])
+    for _ in range(2):
+        got = q.parse_host(lines).to_host()
+        assert_batches_equal(got, expc, f"lines of {reclen} bytes")
+    q.close()
+
+
+@pytest.mark.parametrize("endbz", ["<endl/>", "##", ""])
+def test_terminator_at_every_place_around_a_tile_boundary(port, endbz):
+    # the newline that ends a record, and the end mark in front of it, moved byte by byte across the
+    # boundary between the first and the second tile
+    e = endbz.encode()
+    tail = b"".join(b"<a>%d</a><ab>v%d</ab><b>%d.25</b>" % (i, i, i) + e + b"\n" for i in range(300))
+    for at in range(16384 - 12, 16384 + 12):  # position of the newline
+        head = b"".join(b"<a>%d</a><ab>h</ab><b>1</b>" % i + e + b"\n" for i in range(20))
+        body = at - len(head) - len(b"<a>7</a><ab></ab><b>2.5</b>") - len(e)
+        rec = b"<a>7</a><ab>" + b"w" * body + b"</ab><b>2.5</b>" + e + b"\n"
+        data = head + rec + tail
+        assert data[at] == 10
+        got = gpu_xml(data, cases.SMALL, endbz=endbz)
+        assert_batches_equal(got, port.parse_xml(data, cases.SMALL, endbz=endbz), f"endbz {endbz!r}, newline at {at}")
+
+
 @pytest.mark.parametrize("reclen", [100, 1000, 5000, 8000])
 def test_records_straddling_tiles(port, reclen):
     # records whose start lies far in front of the tile that holds their terminator
