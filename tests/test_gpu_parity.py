@@ -151,6 +151,42 @@ def test_terminator_at_every_place_around_a_tile_boundary(port, endbz):
         assert_batches_equal(got, port.parse_xml(data, cases.SMALL, endbz=endbz), f"endbz {endbz!r}, newline at {at}")
 
 
+@pytest.mark.parametrize("around", [512, 1024, 1536, 2048, 8192, 16320, 16384])
+def test_record_start_around_every_look_behind_threshold(port, around):
+    # the first record of the third tile starts D bytes in front of the tile, D moved byte by byte across
+    # the first look-behind window, its extensions, the capacities of the three launch configurations and
+    # a whole tile (beyond which the record goes to the long-record kernel)
+    filler = b"".join(b"<a>%d</a><ab>f</ab><b>1</b><endl/>\n" % i for i in range(30))
+    tail = b"".join(b"<a>%d</a><ab>v%d</ab><b>%d.25</b><endl/>\n" % (i, i, i) for i in range(300))
+    p = capi.Parser.xml(cases.SMALL)
+    for D in range(around - 9, around + 10):
+        start = 2 * 16384 - D                                   # where the record starts
+        pad = start - len(filler) - len(b"<a>1</a><ab></ab><endl/>\n")
+        a = b"<a>1</a><ab>" + b"p" * pad + b"</ab><endl/>\n"     # ends right in front of `start`
+        b = b"<a>22</a><ab>" + b"q" * D + b"</ab><b>7.5</b><endl/>\n"   # D + 40 bytes: ends in the third tile
+        data = filler + a + b + tail
+        assert len(filler + a) == start
+        got = p.parse_host(data).to_host()
+        assert_batches_equal(got, port.parse_xml(data, cases.SMALL), f"record starts {D} bytes in front of its tile")
+    p.close()
+    # the same geometry with delimited lines (separators of one and of three bytes)
+    for sep in (",", "~!~"):
+        sp = sep.encode()
+        fill = b"".join(sp.join([b"%d" % i, b"f", b"1"]) + b"\n" for i in range(30))
+        rest = b"".join(sp.join([b"%d" % i, b"v%d" % i, b"%d.25" % i]) + b"\n" for i in range(300))
+        q = capi.Parser.csv(sep, 3, typed=[schema.T_I64, schema.T_NONE, schema.T_F64])
+        for D in range(around - 9, around + 10):
+            start = 2 * 16384 - D
+            a = b"1" + sp + b"p" * (start - len(fill) - 2 - len(sp)) + b"\n"
+            b = b"22" + sp + b"q" * D + sp + b"7.5\n"
+            data = fill + a + b + rest
+            assert len(fill + a) == start
+            got = q.parse_host(data).to_host()
+            exp = port.parse_csv(data, sep, 3, typed=[schema.T_I64, schema.T_NONE, schema.T_F64])
+            assert_batches_equal(got, exp, f"line starts {D} bytes in front of its tile, separator {sep!r}")
+        q.close()
+
+
 @pytest.mark.parametrize("reclen", [100, 1000, 5000, 8000])
 def test_records_straddling_tiles(port, reclen):
     # records whose start lies far in front of the tile that holds their terminator
