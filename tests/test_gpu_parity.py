@@ -329,6 +329,35 @@ def test_record_that_starts_in_the_first_bytes_of_the_look_behind(port, endbz):
         assert_batches_equal(got, port.parse_xml(data, cases.SMALL, endbz=endbz), f"endbz {endbz!r}, d {d}")
 
 
+def test_column_bytes_around_the_staging_capacity(port):
+    # a column's bytes of one batch around what a wave's staging area holds (1,536 bytes; 1,280 for inputs
+    # of short records; 960 in the full write kernel): staged and copied out, or stored cell by cell
+    for reclen, cells in ((256, range(20, 29)), (172, range(12, 19)), (128, range(8, 13))):
+        for L in cells:
+            recs = [b"<a>%04d</a><ab>" % (i % 10000) + bytes([65 + (i + k) % 26 for k in range(L)]) + b"</ab><b>1.5</b>" for i in range(1500)]
+            recs = [r + b"x" * (reclen - len(r) - 8) + b"<endl/>\n" for r in recs]
+            data = b"".join(recs)
+            got = gpu_xml(data, cases.SMALL)
+            assert_batches_equal(got, port.parse_xml(data, cases.SMALL), f"records of {reclen} bytes, cells of {L}")
+    for L in range(8, 13):  # 128 lines to a batch
+        lines = b"".join(b"%04d,%s,1.5\n" % (i % 10000, bytes([65 + (i + k) % 26 for k in range(L)]) + b" " * (50 - L)) for i in range(3000))
+        got = gpu_csv(lines, ",", 3, bdelspace=True)
+        assert_batches_equal(got, port.parse_csv(lines, ",", 3, bdelspace=True), f"lines with fields of {L}")
+
+
+def test_separators_per_tile_around_the_list_capacity(port):
+    # lines of 12 and 13 bytes with two separators each, mixed so that the tiles hold from fewer to more
+    # separators than the sizing pass lists (2,568): the parallel field builder or the walk per tile
+    rng = np.random.default_rng(11)
+    for share in (0.0, 0.2, 0.5, 0.8, 1.0):
+        lines = []
+        for i in range(20000):
+            lines.append(b"ab%02d,cd,efg\n" % (i % 100) if rng.random() < share else b"ab%02d,cd,ef\n" % (i % 100))
+        data = b"".join(lines)
+        got = gpu_csv(data, ",", 3)
+        assert_batches_equal(got, port.parse_csv(data, ",", 3), f"share of 13-byte lines {share}")
+
+
 def test_long_cells_bypass_staging(port):
     # cells larger than the LDS staging area take the direct store path
     recs = [b"<ab>" + bytes([65 + (i % 26)]) * 3000 + b"</ab><a>k%d</a><endl/>\n" % i for i in range(30)]
