@@ -27,13 +27,13 @@
 #include "mdc_parse.h"
 
 namespace mdc {
-hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t stream);
-hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream);
+hipError_t launch_tile_kernel(bool write, const TileParams &P, const OutPtrs &O, hipStream_t stream);
+hipError_t launch_emit_kernel(const TileParams &P, const OutPtrs &O, hipStream_t stream);
 hipError_t launch_template_kernel(const TileParams &P, hipStream_t stream);
-hipError_t launch_long_records(bool write, const TileParams &P, uint32_t count, hipStream_t stream);
+hipError_t launch_long_records(bool write, const TileParams &P, const OutPtrs &O, uint32_t count, hipStream_t stream);
 uint32_t scan_segments(uint32_t ntiles);
 hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt, uint64_t *report,
-                             hipStream_t stream);
+                             const uint64_t *status, uint32_t report_status, hipStream_t stream);
 hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_t *const *bytes,
                              uint64_t *const *val, uint32_t *valid, const uint32_t *found, uint64_t rows,
                              uint32_t ncols, hipStream_t stream);
@@ -208,6 +208,7 @@ struct mdc_parser {
     // pinned: h_report mirrors the head of d_status (status words, then from REPORT_TOTALS on the
     // ncols+1 totals, where h_totals points); behind it the batch's pointer table on its way to the device
     uint64_t *h_report = nullptr;
+    uint64_t *h_report_dev = nullptr;  // the same memory as the device addresses it
     uint64_t *h_totals = nullptr;
     void **h_ptrs = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // sizing begins, ends, scan ends, write ends, write begins
@@ -244,6 +245,8 @@ struct mdc_batch {
 };
 
 static uint32_t round16(uint32_t v) { return (v + 15) & ~15u; }
+
+static const OutPtrs g_no_out{};  // the sizing pass writes to no output array
 
 // five blocks per CU fit when a block asks for at most this much LDS (measured: 31.6 KB does, 32.2 KB does not)
 static const uint32_t LDS_FIVE_BLOCKS = 31 * 1024 + 256;
@@ -529,6 +532,7 @@ static int parser_finish(mdc_parser *p, const mdc_opts *opts) {
     HIP_TRY(hipMemset(p->d_tmpl, 0, (1 + TMPL_MAX) * 16 + MAX_COLS * 8 + 16));
     HIP_TRY(hipHostMalloc((void **)&p->h_report, (REPORT_TOTALS + MAX_COLS + 8 + 3 * MAX_COLS) * sizeof(uint64_t),
                           hipHostMallocDefault));
+    HIP_TRY(hipHostGetDevicePointer((void **)&p->h_report_dev, p->h_report, 0));
     p->h_totals = p->h_report + REPORT_TOTALS;
     p->h_ptrs = (void **)(p->h_totals + MAX_COLS + 8);
     for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&p->ev[i]));
@@ -808,7 +812,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         const bool build_tmpl = P.use_tmpl && !p->tmpl_valid && ntiles;
         if (build_tmpl) HIP_TRY(launch_template_kernel(P, s));
         P.schema_bytes = P.p10_off;  // (the sizing pass converts nothing: the schema without the powers of ten)
-        HIP_TRY(launch_tile_kernel(false, P, s));
+        HIP_TRY(launch_tile_kernel(false, P, g_no_out, s));
         P.schema_bytes = (uint32_t)p->blob.size();
         if (p->skew_tile >= 0 && (size_t)p->skew_tile < ntiles && p->skew_col >= 0 && p->skew_col < (int)ncols) {
             uint32_t *w = d_counts + (size_t)p->skew_tile * ncnt + p->skew_col, v = 0;
@@ -819,10 +823,10 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
             p->skew_tile = -1;
         }
         HIP_TRY(hipEventRecord(p->ev[1], s));
-        HIP_TRY(launch_scan_tiles(d_counts, d_base, (uint32_t)ntiles, ncnt, (uint64_t *)p->d_status + REPORT_TOTALS, s));
+        // (the scan's last kernel writes the totals and the status words into h_report itself)
+        HIP_TRY(launch_scan_tiles(d_counts, d_base, (uint32_t)ntiles, ncnt, p->h_report_dev + REPORT_TOTALS,
+                                  (const uint64_t *)p->d_status, (uint32_t)REPORT_TOTALS, s));
         HIP_TRY(hipEventRecord(p->ev[2], s));
-        // status words and totals with one copy
-        HIP_TRY(hipMemcpyAsync(p->h_report, p->d_status, (REPORT_TOTALS + ncnt) * 8, hipMemcpyDeviceToHost, s));
         if (build_tmpl) HIP_TRY(hipMemcpyAsync(p->h_totals + ncnt + 1, p->d_tmpl, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (P.use_tmpl && ntiles) {
@@ -844,10 +848,10 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         }
         if (nlong) {
             // their cells' lengths enter the tiles' counters; then the prefixes and totals again
-            HIP_TRY(launch_long_records(false, P, nlong, s));
-            HIP_TRY(launch_scan_tiles(d_counts, d_base, (uint32_t)ntiles, ncnt, (uint64_t *)p->d_status + REPORT_TOTALS, s));
+            HIP_TRY(launch_long_records(false, P, g_no_out, nlong, s));
+            HIP_TRY(launch_scan_tiles(d_counts, d_base, (uint32_t)ntiles, ncnt, p->h_report_dev + REPORT_TOTALS,
+                                      (const uint64_t *)p->d_status, (uint32_t)REPORT_TOTALS, s));
             HIP_TRY(hipEventRecord(p->ev[2], s));
-            HIP_TRY(hipMemcpyAsync(p->h_report, p->d_status, (REPORT_TOTALS + ncnt) * 8, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
         }
         break;
@@ -956,8 +960,14 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
             return fail(MDC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));          \
         }                                                                              \
     } while (0)
-    // (from pinned memory that lives until the parser's next call: no wait for the copy here)
-    HIP_TRY_B(hipMemcpyAsync(d_ptrs, hp, 3 * (size_t)ncols * sizeof(void *), hipMemcpyHostToDevice, s));
+    // the write pass's kernels get the pointers as a kernel argument (a copy of the table to the device
+    // would stand between the passes; the second conversion stage, if it runs at all, uploads it)
+    OutPtrs O{};
+    for (uint32_t c = 0; c < ncols; ++c) {
+        O.off[c] = (uint32_t *)hp[c];
+        O.bytes[c] = (uint8_t *)hp[ncols + c];
+        O.val[c] = (uint64_t *)hp[2 * ncols + c];
+    }
     if (ntiles == 0) {
         // nothing to launch: every offset array is the single entry 0
         for (uint32_t c = 0; c < ncols; ++c) HIP_TRY_B(hipMemsetAsync(hp[c], 0, 4, s));
@@ -978,13 +988,13 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         const bool dense = d.RB > n.RB && (per_tile + d.RB - 1) / d.RB < (per_tile + n.RB - 1) / n.RB;
         P.L = dense ? d : n;
     }
-    hipError_t le = launch_emit_kernel(P, s);
+    hipError_t le = launch_emit_kernel(P, O, s);
     P.L = p->Ls[p->lb_level];
     if (le == hipSuccess && unmapped) {
         P.only_unmapped = 1;
-        le = launch_tile_kernel(true, P, s);
+        le = launch_tile_kernel(true, P, O, s);
     }
-    if (le == hipSuccess && nlong) le = launch_long_records(true, P, nlong, s);
+    if (le == hipSuccess && nlong) le = launch_long_records(true, P, O, nlong, s);
     if (le != hipSuccess) {
         batch_release(b);
         return fail(MDC_ERR_HIP, "launch: %s", hipGetErrorString(le));
@@ -999,7 +1009,10 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
     uint32_t st = (uint32_t)p->h_report[0] & ~ST_UNMAPPED;
     if (st & ST_NUMERIC_RANGE) {
         // some floating-point texts need the multi-precision stage
-        le = launch_long_float((const uint8_t *)p->d_blob, P.off, P.bytes, P.val, o_valid, o_found, rows, ncols, s);
+        // (the table from pinned memory that lives until the parser's next call)
+        le = hipMemcpyAsync(d_ptrs, hp, 3 * (size_t)ncols * sizeof(void *), hipMemcpyHostToDevice, s);
+        if (le == hipSuccess)
+            le = launch_long_float((const uint8_t *)p->d_blob, P.off, P.bytes, P.val, o_valid, o_found, rows, ncols, s);
         if (le == hipSuccess) le = hipStreamSynchronize(s);
         if (le != hipSuccess) {
             batch_release(b);

@@ -187,6 +187,15 @@ struct TileParams {
 };
 
 // ------------------------------------------------------------------------------------------
+// The output arrays of a write pass, handed to its kernels as a kernel argument: no copy to the device
+// stands between the two passes for them.  (The second conversion stage, which rarely runs, reads the
+// same pointers from a table in device memory: TileParams::off, bytes, val.)
+struct OutPtrs {
+    uint32_t *off[MAX_COLS];    // -> rows+1
+    uint8_t *bytes[MAX_COLS];
+    uint64_t *val[MAX_COLS];    // (null when untyped)
+};
+
 // writer side (mdc_format.hip): columns -> "<name>value</name>...<endl/>\n" text
 
 // status bits of the formatting kernels

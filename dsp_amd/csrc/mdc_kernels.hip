@@ -1322,7 +1322,7 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
 }
 
 template <bool WRITE>
-__global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
+__global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const OutPtrs O) {
     extern __shared__ __align__(16) uint8_t smem[];
     const LdsLayout &L = P.L;
     uint8_t *sdata = smem + L.data;
@@ -1632,9 +1632,9 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
         }
         for (uint32_t c = tid; c < ncols; c += BLOCK) {
             ColOut o;
-            o.off = P.off[c];
-            o.bytes = P.bytes[c];
-            o.val = P.val[c];
+            o.off = O.off[c];
+            o.bytes = O.bytes[c];
+            o.val = O.val[c];
             o.base = tb[c];
             colout[c] = o;
             coltot[c] = tc[c];
@@ -1643,7 +1643,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
     }
     if (WRITE && blockIdx.x == 0) {
         if (tid == 0 && P.rec_off) P.rec_off[0] = 0;
-        for (uint32_t c = tid; c < ncols; c += BLOCK) P.off[c][0] = 0;
+        for (uint32_t c = tid; c < ncols; c += BLOCK) O.off[c][0] = 0;
     }
     if (tid == 0) recend[0] = (uint32_t)(s0_li - 1);
     const uint32_t seplen = H->sep_len;
@@ -2185,7 +2185,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P) {
 // MANY: the instance for inputs whose tiles take several batches (batches of a multiple of 64 records):
 // later batches' map words come straight into LDS, see below.
 template <bool SPECIAL, bool MANY>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void emit_kernel(const TileParams P) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void emit_kernel(const TileParams P, const OutPtrs O) {
     extern __shared__ __align__(16) uint8_t smem[];
     const LdsLayout &L = P.L;
     uint8_t *sdata = smem + L.data;
@@ -2199,7 +2199,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     const uint32_t ncols = P.ncols, W = P.words;
     if (tile == 0) {
         if (tid == 0 && P.rec_off) P.rec_off[0] = 0;
-        for (uint32_t c = tid; c < ncols; c += BLOCK) P.off[c][0] = 0;
+        for (uint32_t c = tid; c < ncols; c += BLOCK) O.off[c][0] = 0;
     }
     // Everything the block needs is requested before anything is waited for: the tile's header
     // words, the tile itself, the first look-behind window and the tile's slice of the cell map
@@ -2292,9 +2292,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         const uint4 sv = g[si];
         const uint64_t pv = gp[pi];
         ColOut o;
-        o.off = P.off[cc];
-        o.bytes = P.bytes[cc];
-        o.val = P.val[cc];
+        o.off = O.off[cc];
+        o.bytes = O.bytes[cc];
+        o.val = O.val[cc];
         o.base = tb[cc];
         const uint32_t szv = P.tile_counts[(uint64_t)tile * (ncols + 1) + cc];
         s[si] = sv;
@@ -2305,9 +2305,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         colout[cc] = o;
         for (uint32_t c = lane + 64; c < ncols; c += 64) {  // schemas with more than 64 columns
             ColOut o2;
-            o2.off = P.off[c];
-            o2.bytes = P.bytes[c];
-            o2.val = P.val[c];
+            o2.off = O.off[c];
+            o2.bytes = O.bytes[c];
+            o2.val = O.val[c];
             o2.base = tb[c];
             tiletot[c] = 0;
             sized[c] = P.tile_counts[(uint64_t)tile * (ncols + 1) + c];
@@ -2486,7 +2486,7 @@ __device__ __forceinline__ bool level_pass(uint32_t b, uint32_t lvl) {
 }
 
 template <bool WRITE>
-__global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P) {
+__global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P, const OutPtrs O) {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ uint32_t sh[8];
     __shared__ uint32_t wsum[BLOCK / 64];
@@ -2709,7 +2709,7 @@ __global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P) 
             len = cut;
         }
         // the filtered length, and with WRITE the surviving bytes in order
-        uint8_t *dst = WRITE ? P.bytes[c] + tb[c] : nullptr;
+        uint8_t *dst = WRITE ? O.bytes[c] + tb[c] : nullptr;
         uint32_t flen = 0;  // (block-uniform running total)
         for (uint32_t k0 = 0; k0 < len; k0 += BLOCK * CHUNK) {
             const uint32_t kb = k0 + tid * CHUNK;
@@ -2740,8 +2740,8 @@ __global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P) 
                 P.long_len[(uint64_t)blockIdx.x * ncols + c] = flen;
                 P.tile_counts[(uint64_t)R.tile * (ncols + 1) + c] += flen;  // (this record is no other block's)
             } else {
-                P.off[c][row + 1] = (uint32_t)(tb[c] + flen);
-                if (typed != T_NONE) P.val[c][row] = 0;
+                O.off[c][row + 1] = (uint32_t)(tb[c] + flen);
+                if (typed != T_NONE) O.val[c][row] = 0;
             }
         }
     }
@@ -2757,7 +2757,7 @@ __global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P) 
     }
 }
 
-hipError_t launch_long_records(bool write, const TileParams &P, uint32_t count, hipStream_t stream) {
+hipError_t launch_long_records(bool write, const TileParams &P, const OutPtrs &O, uint32_t count, hipStream_t stream) {
     if (count == 0) return hipSuccess;
     const uint32_t lds = ((P.schema_bytes + 15) & ~15u) + 5 * P.ncols * 4 + 64;
     if (lds > 48 * 1024) {  // (beside the kernel's few static words)
@@ -2766,9 +2766,9 @@ hipError_t launch_long_records(bool write, const TileParams &P, uint32_t count, 
         if (e != hipSuccess) return e;
     }
     if (write)
-        hipLaunchKernelGGL(long_record_kernel<true>, dim3(count), dim3(BLOCK), lds, stream, P);
+        hipLaunchKernelGGL(long_record_kernel<true>, dim3(count), dim3(BLOCK), lds, stream, P, O);
     else
-        hipLaunchKernelGGL(long_record_kernel<false>, dim3(count), dim3(BLOCK), lds, stream, P);
+        hipLaunchKernelGGL(long_record_kernel<false>, dim3(count), dim3(BLOCK), lds, stream, P, O);
     return hipGetLastError();
 }
 
@@ -2820,8 +2820,12 @@ __global__ __launch_bounds__(1024) void scan_local_kernel(const uint32_t *counts
     if (threadIdx.x == 0) segtot[(uint64_t)seg * ncnt + j] = total;
 }
 
+// report (may be null): where the host reads the totals, memory of the host that the device writes
+// to directly, and in front of them (report_status words back) the two status words of the sizing
+// pass, which this kernel passes on: the host needs no copy between the passes, only the wait.
 __global__ __launch_bounds__(1024) void scan_add_kernel(uint64_t *base, const uint64_t *segtot, uint32_t ntiles,
-                                                        uint32_t ncnt, uint64_t *report) {
+                                                        uint32_t ncnt, uint64_t *report, const uint64_t *status,
+                                                        uint32_t report_status) {
     __shared__ uint64_t wtot[16];
     const uint32_t seg = blockIdx.x, j = blockIdx.y;
     uint64_t part = 0;
@@ -2836,7 +2840,11 @@ __global__ __launch_bounds__(1024) void scan_add_kernel(uint64_t *base, const ui
     if (seg == gridDim.x - 1 && threadIdx.x == 0) {
         const uint64_t tot = pre + segtot[(uint64_t)seg * ncnt + j];
         base[(uint64_t)ntiles * ncnt + j] = tot;
-        if (report) report[j] = tot;  // (beside the status words: the host fetches both with one copy)
+        if (report) report[j] = tot;
+        if (report && status && j == 0) {
+            report[-(int)report_status] = status[0];
+            report[1 - (int)report_status] = status[1];
+        }
     }
 }
 
@@ -2906,12 +2914,12 @@ hipError_t launch_long_float(const uint8_t *schema, uint32_t *const *off, uint8_
     return hipGetLastError();
 }
 
-hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream) {
+hipError_t launch_emit_kernel(const TileParams &P, const OutPtrs &O, hipStream_t stream) {
     if (P.ntiles == 0) return hipSuccess;
     if (!P.cellmap || !P.map_stride) return hipSuccess;  // no map at all: the full write kernel does every tile
     // (schemas with time or binary32 columns take the instance that converts them on the spot)
     const bool many = (P.L.RB & 63u) == 0;  // (the layout for inputs of short records)
-    void (*const fn)(const TileParams) = P.special_cols ? (many ? emit_kernel<true, true> : emit_kernel<true, false>)
+    void (*const fn)(const TileParams, const OutPtrs) = P.special_cols ? (many ? emit_kernel<true, true> : emit_kernel<true, false>)
                                                         : (many ? emit_kernel<false, true> : emit_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -2919,7 +2927,7 @@ hipError_t launch_emit_kernel(const TileParams &P, hipStream_t stream) {
 #ifdef MDC_ABLATE
     if (const char *e = getenv("MDC_DEBUG_LDS")) lds = (uint32_t)atoi(e);  // occupancy experiments
 #endif
-    hipLaunchKernelGGL(fn, dim3(P.ntiles), dim3(BLOCK), lds, stream, P);
+    hipLaunchKernelGGL(fn, dim3(P.ntiles), dim3(BLOCK), lds, stream, P, O);
     return hipGetLastError();
 }
 
@@ -2930,7 +2938,7 @@ hipError_t launch_template_kernel(const TileParams &P, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t stream) {
+hipError_t launch_tile_kernel(bool write, const TileParams &P, const OutPtrs &O, hipStream_t stream) {
     if (P.ntiles == 0) return hipSuccess;
     // per device and cheap: set on every launch so that each GPU of a process gets it
     const void *fn = write ? (const void *)tile_kernel<true> : (const void *)tile_kernel<false>;
@@ -2941,9 +2949,9 @@ hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t strea
     if (const char *e = getenv("MDC_DEBUG_LDS")) lds = (uint32_t)atoi(e);  // occupancy experiments
 #endif
     if (write)
-        hipLaunchKernelGGL(tile_kernel<true>, dim3(P.ntiles), dim3(BLOCK), lds, stream, P);
+        hipLaunchKernelGGL(tile_kernel<true>, dim3(P.ntiles), dim3(BLOCK), lds, stream, P, O);
     else
-        hipLaunchKernelGGL(tile_kernel<false>, dim3(P.ntiles), dim3(BLOCK), lds, stream, P);
+        hipLaunchKernelGGL(tile_kernel<false>, dim3(P.ntiles), dim3(BLOCK), lds, stream, P, O);
     return hipGetLastError();
 }
 
@@ -2951,12 +2959,12 @@ hipError_t launch_tile_kernel(bool write, const TileParams &P, hipStream_t strea
 uint32_t scan_segments(uint32_t ntiles) { return ntiles ? (ntiles + SCAN_SEG - 1) / SCAN_SEG : 1; }
 
 hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt, uint64_t *report,
-                             hipStream_t stream) {
+                             const uint64_t *status, uint32_t report_status, hipStream_t stream) {
     const uint32_t nseg = scan_segments(ntiles);
     uint64_t *segtot = base + (uint64_t)(ntiles + 1) * ncnt;
     hipLaunchKernelGGL(scan_local_kernel, dim3(nseg, ncnt), dim3(1024), 0, stream, counts, base, segtot, ntiles, ncnt);
     hipLaunchKernelGGL(scan_add_kernel, dim3(nseg, ncnt), dim3(1024), 0, stream, base, segtot, ntiles, ncnt,
-                       report);
+                       report, status, report_status);
     return hipGetLastError();
 }
 
