@@ -81,6 +81,7 @@ static int fail(int code, const char *fmt, ...) {
 // d_status: two status words, the diagnostic builds' counters from byte 16 on, and from u64
 // index REPORT_TOTALS on the totals that the scan writes for the host
 static const size_t REPORT_TOTALS = 32;
+static const size_t REPORT_FLAGS = 8;  // (word index: 32 flag bytes of the write pass)
 static_assert(NOALLOC_SCRATCH_BYTES == MDC_NOALLOC_SCRATCH_BYTES, "the header states the size of the static scratch array");
 static const size_t STATUS_BYTES = (REPORT_TOTALS + MAX_COLS + 8) * 8;
 
@@ -979,6 +980,10 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
     P.val = (uint64_t *const *)((void **)d_ptrs + 2 * ncols);
     P.valid = o_valid;
     P.found = o_found;
+    // the write pass reports through 32 bytes of the pinned report, one per status bit
+    volatile uint8_t *host_flags = (volatile uint8_t *)(p->h_report + REPORT_FLAGS);
+    for (uint32_t i = 0; i < 32; ++i) host_flags[i] = 0;
+    P.host_flags = (uint8_t *)(p->h_report_dev + REPORT_FLAGS);
     HIP_TRY_B(hipEventRecord(p->ev[4], s));
     // tiles with a complete cell map take the short write kernel, the others the full one
     {
@@ -1000,13 +1005,15 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         return fail(MDC_ERR_HIP, "launch: %s", hipGetErrorString(le));
     }
     HIP_TRY_B(hipEventRecord(p->ev[3], s));
-    HIP_TRY_B(hipMemcpyAsync(p->h_report, p->d_status, 4, hipMemcpyDeviceToHost, s));
     // (asked for here, while the write pass runs, not between the passes where the GPU would wait)
     (void)hipEventElapsedTime(&t.count_ms, p->ev[0], p->ev[1]);
     (void)hipEventElapsedTime(&t.scan_ms, p->ev[1], p->ev[2]);
     HIP_TRY_B(hipStreamSynchronize(s));
 #undef HIP_TRY_B
+    // what the sizing pass reported, and what the write pass raised in the flag bytes
     uint32_t st = (uint32_t)p->h_report[0] & ~ST_UNMAPPED;
+    for (uint32_t i = 0; i < 32; ++i)
+        if (host_flags[i]) st |= 1u << i;
     if (st & ST_NUMERIC_RANGE) {
         // some floating-point texts need the multi-precision stage
         // (the table from pinned memory that lives until the parser's next call)

@@ -180,6 +180,7 @@ struct TileParams {
     uint32_t *long_len;          // [ntiles][ncols] bytes of each long record's cells
     uint32_t only_unmapped;      // write kernel: leave the mapped tiles to the emit kernel
     uint32_t *tmpl;              // tag template (always a valid pointer; word 0 == 0: none)
+    uint8_t *host_flags;         // write pass: one byte per status bit in memory of the host (null: sizing pass)
     uint32_t use_tmpl;           // tagged input: the sizing pass may use the template
     uint32_t special_cols;       // the schema has time or binary32 columns (picks the write kernel's instance)
     uint32_t tmpl_sample;        // which record the template kernel samples: 0 = the second of the input, 1 = the third ...

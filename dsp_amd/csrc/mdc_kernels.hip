@@ -1079,6 +1079,14 @@ __device__ __forceinline__ void win_or(uint8_t *area, uint32_t x, uint64_t lo, u
     }
 }
 
+// Raises a status bit: in the device's status word and, for the write pass, by the first thread that
+// raises it, in the flag bytes that lie in memory of the host (which reads them after the wait for
+// the stream, without a copy).
+__device__ __forceinline__ void raise_status(const TileParams &P, uint32_t bit) {
+    const uint32_t old = atomicOr(P.status, bit);
+    if (!(old & bit) && P.host_flags) P.host_flags[__builtin_ctz(bit)] = 1;
+}
+
 constexpr int RB_PASSES = 2;  // records per batch <= 64 * RB_PASSES
 
 // descriptor of one cell: source start (15 bits) | source length (15 bits) | filter level (2)
@@ -1627,7 +1635,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
         // what the sizing pass counted for this tile: the rows must agree before anything is stored
         const uint32_t *tc = P.tile_counts + (uint64_t)blockIdx.x * (ncols + 1);
         if (tc[ncols] != nrec_all) {
-            if (tid == 0) atomicOr(P.status, ST_INTERNAL);
+            if (tid == 0) raise_status(P, ST_INTERNAL);
             return;
         }
         for (uint32_t c = tid; c < ncols; c += BLOCK) {
@@ -2130,8 +2138,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
                                                              coltot[c] - done, overrun);
             if (lane == 0) tiletot[c] = done + total;  // this wave owns column c
         }
-        if (WRITE && deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
-        if (WRITE && overrun) atomicOr(P.status, ST_INTERNAL);
+        if (WRITE && deferred) raise_status(P, ST_NUMERIC_RANGE);
+        if (WRITE && overrun) raise_status(P, ST_INTERNAL);
         __syncthreads();
         STAMP(5);  // cells: descriptors, lengths, values, staging, copy-out
         if (mapping && (uint32_t)tid < RBn)
@@ -2158,7 +2166,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
     if (WRITE) {
         // (the batch loop ends with a barrier) every column must have come out as long as it was sized
         for (uint32_t c = tid; c < ncols; c += BLOCK)
-            if (tiletot[c] != coltot[c]) atomicOr(P.status, ST_INTERNAL);
+            if (tiletot[c] != coltot[c]) raise_status(P, ST_INTERNAL);
     }
     if (!WRITE) {
         if (tmode && irregular && tid == 0) atomicAdd(P.status + 1, 1u);  // the host renews a template few tiles follow
@@ -2444,12 +2452,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             __syncthreads();  // the next batch reuses the bitmaps (and, fetched by all waves, the map)
         }
     }
-    if (deferred) atomicOr(P.status, ST_NUMERIC_RANGE);
+    if (deferred) raise_status(P, ST_NUMERIC_RANGE);
     // (behind the barrier that follows the last batch's columns) every column must have come out
     // as long as it was sized
     bool differ = overrun;
     for (uint32_t c = tid; c < ncols; c += BLOCK) differ |= tiletot[c] != sized[c];
-    if (differ && !SKIP(16)) atomicOr(P.status, ST_INTERNAL);
+    if (differ && !SKIP(16)) raise_status(P, ST_INTERNAL);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2537,7 +2545,7 @@ __global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P, 
         hi = lo;
     }
     if (gend - gstart >= ((int64_t)1 << 31)) {
-        if (tid == 0) atomicOr(P.status, ST_RECORD_TOO_LONG);
+        if (tid == 0) raise_status(P, ST_RECORD_TOO_LONG);
         return;
     }
     const uint32_t reclen = (uint32_t)(gend - gstart);  // the record's text: the '\n' is not part of it
@@ -2753,7 +2761,7 @@ __global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P, 
             P.valid[row * W + tid] = 0;
         }
         if (tid == 0 && P.rec_off) P.rec_off[row + 1] = (uint64_t)gend + 1;
-        if (deferred && tid == 0) atomicOr(P.status, ST_NUMERIC_RANGE);
+        if (deferred && tid == 0) raise_status(P, ST_NUMERIC_RANGE);
     }
 }
 
