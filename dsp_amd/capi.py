@@ -31,6 +31,7 @@ MDC_ERR_NUMERIC = -7
 MDC_ERR_IO = -8
 MDC_ERR_INTERNAL = -9
 MDC_F_NO_RECOFF = 1
+MDC_F_ONE_PASS = 2
 
 # every symbol include/mdc_parse.h declares
 EXPORTS = [
@@ -84,6 +85,8 @@ class CTiming(ctypes.Structure):
         ("full_write", ctypes.c_int),
         ("lookup_tiles", ctypes.c_int),
         ("long_records", ctypes.c_int),
+        ("one_pass", ctypes.c_int),
+        ("one_pass_redone", ctypes.c_int),
     ]
 
 

@@ -27,7 +27,7 @@
 #include "mdc_parse.h"
 
 namespace mdc {
-hipError_t launch_tile_kernel(bool write, const TileParams &P, const OutPtrs &O, hipStream_t stream);
+hipError_t launch_tile_kernel(int mode, const TileParams &P, const OutPtrs &O, hipStream_t stream);
 hipError_t launch_emit_kernel(const TileParams &P, const OutPtrs &O, hipStream_t stream);
 hipError_t launch_template_kernel(const TileParams &P, hipStream_t stream);
 hipError_t launch_long_records(bool write, const TileParams &P, const OutPtrs &O, uint32_t count, hipStream_t stream);
@@ -191,6 +191,15 @@ struct mdc_parser {
     LdsLayout LEs[3]{}; // ... and the emit kernel's
     LdsLayout LEd[3]{}; // ... for inputs of short records
     LdsLayout LSs[3]{}; // ... and the sizing pass's
+    LdsLayout LF{};     // the one-pass parse's (first look-behind level only)
+    // one-pass parse: counts published from tile to tile ((ncols + 1) x ws_tiles words) and what the output
+    // arrays hold; the output sizes are guessed from the previous parse's bytes per input byte
+    uint64_t *d_pub = nullptr;
+    uint64_t *d_caps = nullptr;
+    std::vector<double> est_bpb;
+    bool est_valid = false;
+    int fused_hold = 0;          // parses that stay with two passes after a one-pass parse had to be repeated
+    bool one_pass = false;       // MDC_F_ONE_PASS, or MDC_ONE_PASS in the environment
     int lb_level = 0;   // level that fitted the previous parse
     // workspace
     uint32_t *d_counts = nullptr;
@@ -260,6 +269,8 @@ static const uint32_t LDS_SIX_BLOCKS = 25 * 1024 + 512;
 // they fit, since such records are short (a list of 2,568 instead of 3,072 separators pays for that).
 static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32_t blob_bytes, uint32_t lbmax,
                            LdsLayout &L, bool lean = false, bool sizing = false) {
+    // (a write kernel that follows the tag template needs the row masks and the template side by side)
+    const bool own_tmpl = npat && !sizing;
     uint32_t RB = sizing && !npat ? 128 : 112;
     for (;;) {
         uint32_t o = 0;
@@ -280,9 +291,16 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         L.fmask = o;
         o += round16(RB * words * 4);
         L.coltot = o;
+        L.tmpl = L.vmask;
+        L.tmpl_bytes = L.coltot - L.vmask;
         o += round16(2 * (ncols + 1) * 4);
         L.colout = o;
         if (!lean && !sizing) o += round16(ncols * 32);
+        if (own_tmpl) {
+            L.tmpl = o;
+            L.tmpl_bytes = round16((RB + 2) * 2) + round16(ncols * 8) + 16 * 40;
+            o += L.tmpl_bytes;
+        }
         L.schema = o;
         o += round16(blob_bytes);
         L.misc = o;
@@ -327,6 +345,51 @@ static void compute_emit_layout(uint32_t ncols, uint32_t words, uint32_t lbmax, 
         L.RB = RB;
         if (o <= LDS_FIVE_BLOCKS || RB <= 8) break;
         if (RB > 64 && lbmax > 1536) break;
+        RB = RB > 16 ? RB - 8 : RB / 2;
+    }
+}
+
+// The one-pass parse's LDS (tagged input): the sizing pass's regions with the row masks and the template side
+// by side, the ends of the cells within their columns, and what is left of a four-blocks-per-CU share as
+// the staging area of the whole tile's cell bytes.
+static const uint32_t LDS_FOUR_BLOCKS = 40 * 1024 - 768;
+static void compute_fused_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32_t blob_bytes, uint32_t lbmax,
+                                 LdsLayout &L) {
+    uint32_t RB = 112;
+    for (;;) {
+        uint32_t o = 0;
+        L = LdsLayout{};
+        L.lbmax = lbmax;
+        L.data = o;
+        o += round16(TILE + lbmax + DATA_SLACK);
+        L.evt = o;
+        o += round16(npat ? (RB * npat + 1) / 2 * 4 : RB * (ncols + 2) * 4);
+        L.recend = o;
+        o += round16((RB + 1) * 4);
+        L.vmask = o;
+        o += round16(RB * words * 4);
+        L.fmask = o;
+        o += round16(RB * words * 4);
+        L.coltot = o;
+        o += round16(2 * (ncols + 1) * 4);
+        L.colout = o;
+        L.endl = o;
+        o += round16(RB * ncols * 2);
+        L.tmpl = o;
+        L.tmpl_bytes = round16((RB + 2) * 2) + round16(ncols * 8) + 16 * 40;
+        o += L.tmpl_bytes;
+        L.schema = o;
+        o += round16(blob_bytes);
+        L.misc = o;
+        o += 128;
+        L.evlist = o;
+        L.evcap = 0;
+        const uint32_t room = o < LDS_FOUR_BLOCKS ? (LDS_FOUR_BLOCKS - o) & ~15u : 0;
+        L.stage_cap = room > 16384 ? 16384 : room;
+        o += L.stage_cap;
+        L.total = o;
+        L.RB = RB;
+        if (L.stage_cap >= 64 * RB || RB <= 8) break;  // (about 64 bytes of cells a record)
         RB = RB > 16 ? RB - 8 : RB / 2;
     }
 }
@@ -512,6 +575,7 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
         if (p->Ls[lv].total > 160 * 1024)
             return fail(MDC_ERR_ARG, "schema too large for LDS (%u bytes)", p->Ls[lv].total);
     }
+    compute_fused_layout(ncols, npat, p->words, (uint32_t)p->blob.size(), LB_LEVELS[0], p->LF);
     return MDC_OK;
 }
 
@@ -531,7 +595,13 @@ static int parser_finish(mdc_parser *p, const mdc_opts *opts) {
     if (rc) return rc;
     p->d_tmpl = (uint32_t *)st;
     HIP_TRY(hipMemset(p->d_tmpl, 0, (1 + TMPL_MAX) * 16 + MAX_COLS * 8 + 16));
-    HIP_TRY(hipHostMalloc((void **)&p->h_report, (REPORT_TOTALS + MAX_COLS + 8 + 3 * MAX_COLS) * sizeof(uint64_t),
+    rc = dev_alloc(p->dev, (MAX_COLS + 1) * 8, &st);
+    if (rc) return rc;
+    p->d_caps = (uint64_t *)st;
+    p->est_bpb.assign(p->ncols, 0.0);
+    p->one_pass = (p->flags & MDC_F_ONE_PASS) != 0 || getenv("MDC_ONE_PASS") != nullptr;
+    // (status words and flag bytes | totals | pointer table | capacities of the output arrays)
+    HIP_TRY(hipHostMalloc((void **)&p->h_report, (REPORT_TOTALS + MAX_COLS + 8 + 3 * MAX_COLS + MAX_COLS + 8) * sizeof(uint64_t),
                           hipHostMallocDefault));
     HIP_TRY(hipHostGetDevicePointer((void **)&p->h_report_dev, p->h_report, 0));
     p->h_totals = p->h_report + REPORT_TOTALS;
@@ -608,6 +678,8 @@ extern "C" void mdc_parser_destroy(mdc_parser *p) {
         dev_free(p->dev, p->d_hdr);
         dev_free(p->dev, p->d_long);
         dev_free(p->dev, p->d_cellmap);
+        dev_free(p->dev, p->d_pub);
+        dev_free(p->dev, p->d_caps);
         if (p->h_report) (void)hipHostFree(p->h_report);
         for (int i = 0; i < 5; ++i)
             if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
@@ -643,10 +715,12 @@ static int ensure_workspace(mdc_parser *p, size_t ntiles) {
     dev_free(p->dev, p->d_base);
     dev_free(p->dev, p->d_hdr);
     dev_free(p->dev, p->d_long);
+    dev_free(p->dev, p->d_pub);
     p->d_counts = nullptr;
     p->d_base = nullptr;
     p->d_hdr = nullptr;
     p->d_long = nullptr;
+    p->d_pub = nullptr;
     p->ws_tiles = 0;
     size_t ncnt = (size_t)p->ncols + 1;
     void *a = nullptr, *b = nullptr, *h = nullptr;
@@ -664,6 +738,10 @@ static int ensure_workspace(mdc_parser *p, size_t ntiles) {
     }
     p->d_counts = (uint32_t *)a;
     p->d_base = (uint64_t *)b;
+    if (p->mode == MODE_XML && p->one_pass) {
+        void *q = nullptr;
+        if (dev_alloc(p->dev, ntiles * ncnt * 8, &q) == MDC_OK) p->d_pub = (uint64_t *)q;
+    }
     p->ws_tiles = ntiles;
     return MDC_OK;
 }
@@ -711,6 +789,216 @@ static int status_to_error(uint32_t st) {
     return MDC_OK;
 }
 
+// A new batch with room for rows_cap rows and bytes_cap[c] bytes of column c (the two-pass parse asks for
+// exactly what its sizing pass counted, the one-pass parse for a guess with a margin).
+static int alloc_batch(mdc_parser *p, uint64_t rows_cap, const uint64_t *bytes_cap, mdc_batch **out) {
+    Device *d = p->dev;
+    const uint32_t ncols = (uint32_t)p->ncols;
+    mdc_batch *b = new mdc_batch();
+    b->dev = d;
+    b->ncols = (int)ncols;
+    b->words = p->words;
+    b->typed = p->typed;
+    for (auto &c : p->cols) b->collen.push_back(c.collen);
+    b->d_off.assign(ncols, nullptr);
+    b->d_bytes.assign(ncols, nullptr);
+    b->d_val.assign(ncols, nullptr);
+    b->nbytes.assign(ncols, 0);
+    b->h_off.resize(ncols);
+    b->h_bytes.resize(ncols);
+    b->h_val.resize(ncols);
+    b->have_col.assign(ncols, false);
+    b->have_val.assign(ncols, false);
+    b->h_fixed.resize(ncols);
+    b->fixed_stride.assign(ncols, 0);
+    int rc = MDC_OK;
+    void *q = nullptr;
+#define ALLOC_OR_FAIL(bytes, dst, T)     \
+    do {                                 \
+        rc = dev_alloc(d, (bytes), &q);  \
+        if (rc) {                        \
+            batch_release(b);            \
+            return rc;                   \
+        }                                \
+        dst = (T)q;                      \
+    } while (0)
+    if (!(p->flags & MDC_F_NO_RECOFF)) ALLOC_OR_FAIL((rows_cap + 1) * 8, b->d_rec_off, uint64_t *);
+    for (uint32_t c = 0; c < ncols; ++c) {
+        ALLOC_OR_FAIL((rows_cap + 1) * 4, b->d_off[c], uint32_t *);
+        ALLOC_OR_FAIL(bytes_cap[c] + 16, b->d_bytes[c], uint8_t *);
+        if (p->typed[c] != MDC_T_NONE) ALLOC_OR_FAIL(rows_cap * 8 + 8, b->d_val[c], uint64_t *);
+    }
+    ALLOC_OR_FAIL(rows_cap * p->words * 4 + 4, b->d_valid, uint32_t *);
+    ALLOC_OR_FAIL(rows_cap * p->words * 4 + 4, b->d_found, uint32_t *);
+    ALLOC_OR_FAIL(3 * (size_t)ncols * sizeof(void *), b->d_ptrs, void *);
+#undef ALLOC_OR_FAIL
+    *out = b;
+    return MDC_OK;
+}
+
+// algorithmic output bytes of a parse: offsets, cells, values, the two row masks, record offsets
+static uint64_t output_bytes(const mdc_parser *p, uint64_t rows, const uint64_t *totals, bool recoff) {
+    uint64_t out = 2 * rows * p->words * 4 + (recoff ? (rows + 1) * 8 : 0);
+    for (int c = 0; c < p->ncols; ++c) out += (rows + 1) * 4 + totals[c] + (p->typed[c] != MDC_T_NONE ? rows * 8 : 0);
+    return out;
+}
+
+// what the next parse of this parser may expect: rows and bytes of every column per input byte
+static void remember_sizes(mdc_parser *p, size_t n, uint64_t rows, const uint64_t *totals) {
+    if (!n) return;
+    p->rows_per_byte = (double)rows / (double)n;
+    for (int c = 0; c < p->ncols; ++c) p->est_bpb[c] = (double)totals[c] / (double)n;
+    p->est_valid = true;
+}
+
+static const int FUSED_REDO = 1000;  // (private) the one-pass parse was given up: parse in two passes
+
+// The one-pass parse: one launch of the tile kernel that sizes and writes.  The output arrays must exist
+// before anything is counted: the caller's (ext), or a new batch sized from the previous parse's bytes per
+// input byte with a margin.  A tile whose place lies beyond an array stores nothing and raises ST_OVERFLOW;
+// then, after a long record (whose cells this pass cannot count in time) or a tile that gave up waiting,
+// the result is dropped and FUSED_REDO returned.  Tiles that do not take the straight-line write are left,
+// with their places, to the full write kernel.
+static int parse_fused(mdc_parser *p, TileParams P, const mdc_outputs *ext, void *d_ptrs_ext, mdc_batch **out,
+                       int64_t *rows_out, uint64_t *col_bytes) {
+    Device *d = p->dev;
+    hipStream_t s = d->stream;
+    const uint32_t ncols = (uint32_t)p->ncols, ncnt = ncols + 1;
+    const size_t n = (size_t)P.n, ntiles = P.ntiles;
+    mdc_timing &t = p->timing;
+    uint64_t *caps = p->h_totals + MAX_COLS + 8 + 3 * MAX_COLS;  // pinned, behind the pointer table
+    mdc_batch *b = nullptr;
+    void **hp = p->h_ptrs;
+    int rc;
+    if (ext) {
+        for (uint32_t c = 0; c < ncols; ++c) {
+            caps[c] = ext->cols[c].bytes_cap;
+            hp[c] = ext->cols[c].d_off;
+            hp[ncols + c] = ext->cols[c].d_bytes;
+            hp[2 * ncols + c] = p->typed[c] != MDC_T_NONE ? ext->cols[c].d_val : nullptr;
+        }
+        caps[ncols] = (uint64_t)ext->rows_cap;
+    } else {
+        for (uint32_t c = 0; c < ncols; ++c) caps[c] = (uint64_t)(p->est_bpb[c] * (double)n * 1.03) + 65536;
+        caps[ncols] = (uint64_t)(p->rows_per_byte * (double)n * 1.03) + 4096;
+        for (uint32_t c = 0; c < ncols; ++c)
+            if (caps[c] > 0xFFFFFFFFull) return FUSED_REDO;  // (the two-pass parse reports a column beyond 4 GiB)
+        rc = alloc_batch(p, caps[ncols], caps, &b);
+        if (rc) return rc;
+        for (uint32_t c = 0; c < ncols; ++c) {
+            hp[c] = b->d_off[c];
+            hp[ncols + c] = b->d_bytes[c];
+            hp[2 * ncols + c] = b->d_val[c];
+        }
+    }
+    void *d_ptrs = ext ? d_ptrs_ext : b->d_ptrs;
+    OutPtrs O{};
+    for (uint32_t c = 0; c < ncols; ++c) {
+        O.off[c] = (uint32_t *)hp[c];
+        O.bytes[c] = (uint8_t *)hp[ncols + c];
+        O.val[c] = (uint64_t *)hp[2 * ncols + c];
+    }
+    P.rec_off = (p->flags & MDC_F_NO_RECOFF) ? nullptr : ext ? ext->d_rec_off : b->d_rec_off;
+    P.off = (uint32_t *const *)d_ptrs;
+    P.bytes = (uint8_t *const *)((void **)d_ptrs + ncols);
+    P.val = (uint64_t *const *)((void **)d_ptrs + 2 * ncols);
+    P.valid = ext ? ext->d_valid : b->d_valid;
+    P.found = ext ? ext->d_found : b->d_found;
+    P.cellmap = nullptr;
+    P.map_cap = P.map_stride = 0;
+    P.fused_totals = p->h_report_dev + REPORT_TOTALS;
+    volatile uint8_t *host_flags = (volatile uint8_t *)(p->h_report + REPORT_FLAGS);
+    for (uint32_t i = 0; i < 32; ++i) host_flags[i] = 0;
+    for (uint32_t j = 0; j < ncnt; ++j) p->h_totals[j] = 0;
+    P.host_flags = (uint8_t *)(p->h_report_dev + REPORT_FLAGS);
+    P.L = p->LF;
+#define HIP_TRY_B(expr)                                                                \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            batch_release(b);                                                          \
+            return fail(MDC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));          \
+        }                                                                              \
+    } while (0)
+    HIP_TRY_B(hipMemsetAsync(p->d_status, 0, 16, s));
+    HIP_TRY_B(hipMemsetAsync(P.pub, 0, ntiles * ncnt * 8, s));
+    HIP_TRY_B(hipMemcpyAsync((void *)P.caps, caps, ncnt * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY_B(hipEventRecord(p->ev[0], s));
+    HIP_TRY_B(launch_tile_kernel(2, P, O, s));
+    HIP_TRY_B(hipEventRecord(p->ev[3], s));
+    // status word, tiles that left the template, long records, tiles left to the full write kernel
+    uint32_t *hst = (uint32_t *)p->h_report;
+    HIP_TRY_B(hipMemcpyAsync(hst, p->d_status, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY_B(hipStreamSynchronize(s));
+    uint32_t st = 0;
+    for (uint32_t i = 0; i < 32; ++i)
+        if (host_flags[i]) st |= 1u << i;
+    const uint32_t left = hst[1], nlong = hst[2], odd = hst[3];
+    t.lookup_tiles = (int)left;
+    if ((size_t)left * 8 > ntiles) {  // few tiles follow the template: the next (two-pass) parse samples another record
+        p->tmpl_valid = false;
+        p->tmpl_sample = (p->tmpl_sample + 1) % 4;
+    }
+    if ((st & (ST_OVERFLOW | ST_GIVEUP)) || nlong) {
+        batch_release(b);
+        p->fused_hold = nlong ? 16 : 2;
+        return FUSED_REDO;
+    }
+    if ((size_t)odd * 8 > ntiles) p->fused_hold = 16;  // (mostly the full write kernel: two passes do that better)
+    const uint64_t rows = p->h_totals[ncols];
+    if (odd) {
+        // tiles that did not take the straight-line write, at the places this pass found for them
+        for (uint32_t i = 0; i < 32; ++i) host_flags[i] = 0;
+        P.L = p->Ls[0];
+        P.only_unmapped = 1;
+        HIP_TRY_B(launch_tile_kernel(1, P, O, s));
+        HIP_TRY_B(hipEventRecord(p->ev[3], s));
+        HIP_TRY_B(hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < 32; ++i)
+            if (host_flags[i]) st |= 1u << i;
+    }
+    st &= ~ST_UNMAPPED;
+    if (st & ST_NUMERIC_RANGE) {
+        // some floating-point texts need the multi-precision stage
+        hipError_t le = hipMemcpyAsync(d_ptrs, hp, 3 * (size_t)ncols * sizeof(void *), hipMemcpyHostToDevice, s);
+        if (le == hipSuccess)
+            le = launch_long_float((const uint8_t *)p->d_blob, P.off, P.bytes, P.val, P.valid, P.found, rows, ncols, s);
+        if (le == hipSuccess) le = hipStreamSynchronize(s);
+        if (le != hipSuccess) {
+            batch_release(b);
+            return fail(MDC_ERR_HIP, "long_float: %s", hipGetErrorString(le));
+        }
+        st &= ~ST_NUMERIC_RANGE;
+    }
+#undef HIP_TRY_B
+    rc = status_to_error(st);
+    if (rc) {
+        batch_release(b);
+        return rc;
+    }
+    remember_sizes(p, n, rows, p->h_totals);
+    if (b) {
+        b->rows = (int64_t)rows;
+        for (uint32_t c = 0; c < ncols; ++c) b->nbytes[c] = p->h_totals[c];
+    }
+    t.count_ms = t.scan_ms = 0;
+    (void)hipEventElapsedTime(&t.total_ms, p->ev[0], p->ev[3]);
+    t.write_ms = t.total_ms;
+    t.bytes_in = n;
+    t.bytes_out = output_bytes(p, rows, p->h_totals, P.rec_off != nullptr);
+    t.rows = (int64_t)rows;
+    t.tiles = (int)ntiles;
+    t.full_write = odd ? 1 : 0;
+    t.long_records = 0;
+    t.one_pass = 1;
+    t.one_pass_redone = 0;
+    if (out) *out = b;
+    if (rows_out) *rows_out = (int64_t)rows;
+    if (col_bytes)
+        for (uint32_t c = 0; c < ncols; ++c) col_bytes[c] = p->h_totals[c];
+    return MDC_OK;
+}
+
 // One parse of n device-resident bytes.  `ext` == nullptr: the outputs become a new batch (*out)
 // and the workspace is the parser's, grown on demand.  Otherwise (the entry point that allocates
 // nothing) the outputs are the caller's arrays, the workspace is carved out of this device's static
@@ -725,13 +1013,13 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
     const uint32_t ncols = (uint32_t)p->ncols, ncnt = ncols + 1;
     const size_t ntiles = (n + TILE - 1) / TILE;
     uint32_t *d_counts, *d_hdr, *d_cellmap = nullptr;
-    uint64_t *d_base;
+    uint64_t *d_base, *d_pub = nullptr;
     uint8_t *d_long;
     void *d_ptrs_ext = nullptr;
     size_t map_cap = 0, map_stride = 0;
     int rc;
     if (ext) {
-        // tile headers | pointer table | prefixes, totals, segment totals | counters
+        // tile headers | pointer table | prefixes, totals, segment totals | counters | long records | published counts
         const size_t nt = ntiles ? ntiles : 1;
         size_t o = 0;
         const size_t o_hdr = o;
@@ -743,7 +1031,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         const size_t o_counts = o;
         o += (nt * ncnt * 4 + 255) & ~(size_t)255;
         const size_t o_long = o;
-        o += nt * long_bytes_per_tile(p->ncols);
+        o += (nt * long_bytes_per_tile(p->ncols) + 255) & ~(size_t)255;
         if (o > NOALLOC_SCRATCH_BYTES)
             return fail(MDC_ERR_TOO_LARGE,
                         "an input of %zu bytes with %u columns needs %zu bytes of scratch; the static array holds %zu "
@@ -756,6 +1044,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         d_base = (uint64_t *)(sc + o_base);
         d_counts = (uint32_t *)(sc + o_counts);
         d_long = sc + o_long;
+        if (p->one_pass && o + nt * ncnt * 8 <= NOALLOC_SCRATCH_BYTES) d_pub = (uint64_t *)(sc + o);  // (else: two passes)
     } else {
         rc = ensure_workspace(p, ntiles ? ntiles : 1);
         if (rc) return rc;
@@ -766,8 +1055,12 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         d_hdr = p->d_hdr;
         d_long = (uint8_t *)p->d_long;
         d_cellmap = p->d_cellmap;
+        d_pub = p->d_pub;
         map_cap = p->map_cap;
         map_stride = p->map_stride;
+#ifdef MDC_ABLATE
+        if (getenv("MDC_NO_MAP")) map_stride = 0;  // every tile through the full write kernel
+#endif
     }
 
     TileParams P{};
@@ -791,6 +1084,8 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
     P.tmpl = p->d_tmpl;
     P.use_tmpl = p->mode == MODE_XML ? 1u : 0u;
     P.tmpl_sample = p->tmpl_sample;
+    P.pub = d_pub;
+    P.caps = p->d_caps;
     for (int t : p->typed)
         if (t == MDC_T_TIME || t == MDC_T_F32) P.special_cols = 1;
 #ifdef MDC_ABLATE
@@ -799,6 +1094,21 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         if (atoi(dbg) & 1) P.use_tmpl = 0;  // (no tag search: nothing would follow the template)
     if (const char *dbg = getenv("MDC_DEBUG_SKIP")) P.debug = (uint32_t)atoi(dbg);
 #endif
+    mdc_timing &t = p->timing;
+    t.one_pass = t.one_pass_redone = 0;
+
+    // One pass where the previous parse left what it needs: a template the input followed, the first
+    // look-behind level, and (for a new batch) the sizes to expect.
+    if (p->mode == MODE_XML && p->one_pass && d_pub && ntiles && P.use_tmpl && p->tmpl_valid && p->lb_level == 0 &&
+        p->skew_tile < 0 && (ext || p->est_valid)) {
+        if (p->fused_hold > 0) {
+            --p->fused_hold;
+        } else {
+            rc = parse_fused(p, P, ext, d_ptrs_ext, out, rows_out, col_bytes);
+            if (rc != FUSED_REDO) return rc;
+            t.one_pass_redone = 1;
+        }
+    }
 
     hipStream_t s = d->stream;
     // Sizing pass.  The look-behind capacity starts at the level that fitted the previous parse.  A
@@ -813,7 +1123,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         const bool build_tmpl = P.use_tmpl && !p->tmpl_valid && ntiles;
         if (build_tmpl) HIP_TRY(launch_template_kernel(P, s));
         P.schema_bytes = P.p10_off;  // (the sizing pass converts nothing: the schema without the powers of ten)
-        HIP_TRY(launch_tile_kernel(false, P, g_no_out, s));
+        HIP_TRY(launch_tile_kernel(0, P, g_no_out, s));
         P.schema_bytes = (uint32_t)p->blob.size();
         if (p->skew_tile >= 0 && (size_t)p->skew_tile < ntiles && p->skew_col >= 0 && p->skew_col < (int)ncols) {
             uint32_t *w = d_counts + (size_t)p->skew_tile * ncnt + p->skew_col, v = 0;
@@ -860,15 +1170,14 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
     const bool unmapped = ((uint32_t)p->h_report[0] & ST_UNMAPPED) != 0;
     rc = status_to_error((uint32_t)p->h_report[0] & ~(ST_NUMERIC_RANGE | ST_UNMAPPED));
     if (rc) return rc;
-    mdc_timing &t = p->timing;
     const uint64_t rows = p->h_totals[ncols];
     if (n) p->rows_per_byte = (double)rows / (double)n;
     for (uint32_t c = 0; c < ncols; ++c)
         if (p->h_totals[c] > 0xFFFFFFFFull)
             return fail(MDC_ERR_TOO_LARGE, "column %u holds %llu bytes; split the input", c,
                         (unsigned long long)p->h_totals[c]);
+    remember_sizes(p, n, rows, p->h_totals);
 
-    uint64_t bytes_out = 0;
     mdc_batch *b = nullptr;
     uint64_t *o_rec_off = nullptr;
     uint32_t *o_valid = nullptr, *o_found = nullptr;
@@ -886,62 +1195,17 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
             hp[c] = ext->cols[c].d_off;
             hp[ncols + c] = ext->cols[c].d_bytes;
             hp[2 * ncols + c] = p->typed[c] != MDC_T_NONE ? ext->cols[c].d_val : nullptr;
-            bytes_out += (rows + 1) * 4 + p->h_totals[c] + (p->typed[c] != MDC_T_NONE ? rows * 8 : 0);
         }
         o_rec_off = (p->flags & MDC_F_NO_RECOFF) ? nullptr : ext->d_rec_off;
-        if (o_rec_off) bytes_out += (rows + 1) * 8;
         o_valid = ext->d_valid;
         o_found = ext->d_found;
         d_ptrs = d_ptrs_ext;
     } else {
-        b = new mdc_batch();
-        b->dev = d;
+        rc = alloc_batch(p, rows, p->h_totals, &b);
+        if (rc) return rc;
         b->rows = (int64_t)rows;
-        b->ncols = (int)ncols;
-        b->words = p->words;
-        b->typed = p->typed;
-        for (auto &c : p->cols) b->collen.push_back(c.collen);
-        b->d_off.assign(ncols, nullptr);
-        b->d_bytes.assign(ncols, nullptr);
-        b->d_val.assign(ncols, nullptr);
-        b->nbytes.assign(ncols, 0);
-        b->h_off.resize(ncols);
-        b->h_bytes.resize(ncols);
-        b->h_val.resize(ncols);
-        b->have_col.assign(ncols, false);
-        b->have_val.assign(ncols, false);
-        b->h_fixed.resize(ncols);
-        b->fixed_stride.assign(ncols, 0);
-        auto A = [&](size_t bytes, void **q) { return dev_alloc(d, bytes, q); };
-        void *q = nullptr;
-#define ALLOC_OR_FAIL(bytes, dst, T)     \
-    do {                                 \
-        rc = A((bytes), &q);             \
-        if (rc) {                        \
-            batch_release(b);            \
-            return rc;                   \
-        }                                \
-        dst = (T)q;                      \
-    } while (0)
-        if (!(p->flags & MDC_F_NO_RECOFF)) {
-            ALLOC_OR_FAIL((rows + 1) * 8, b->d_rec_off, uint64_t *);
-            bytes_out += (rows + 1) * 8;
-        }
         for (uint32_t c = 0; c < ncols; ++c) {
             b->nbytes[c] = p->h_totals[c];
-            ALLOC_OR_FAIL((rows + 1) * 4, b->d_off[c], uint32_t *);
-            ALLOC_OR_FAIL(b->nbytes[c] + 16, b->d_bytes[c], uint8_t *);
-            bytes_out += (rows + 1) * 4 + b->nbytes[c];
-            if (p->typed[c] != MDC_T_NONE) {
-                ALLOC_OR_FAIL(rows * 8 + 8, b->d_val[c], uint64_t *);
-                bytes_out += rows * 8;
-            }
-        }
-        ALLOC_OR_FAIL(rows * p->words * 4 + 4, b->d_valid, uint32_t *);
-        ALLOC_OR_FAIL(rows * p->words * 4 + 4, b->d_found, uint32_t *);
-        ALLOC_OR_FAIL(3 * (size_t)ncols * sizeof(void *), b->d_ptrs, void *);
-#undef ALLOC_OR_FAIL
-        for (uint32_t c = 0; c < ncols; ++c) {
             hp[c] = b->d_off[c];
             hp[ncols + c] = b->d_bytes[c];
             hp[2 * ncols + c] = b->d_val[c];
@@ -951,7 +1215,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         o_found = b->d_found;
         d_ptrs = b->d_ptrs;
     }
-    bytes_out += 2 * rows * p->words * 4;
+    const uint64_t bytes_out = output_bytes(p, rows, p->h_totals, o_rec_off != nullptr);
     // from here on a failed runtime call gives the half-built batch back before it returns
 #define HIP_TRY_B(expr)                                                                \
     do {                                                                               \
@@ -997,7 +1261,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
     P.L = p->Ls[p->lb_level];
     if (le == hipSuccess && unmapped) {
         P.only_unmapped = 1;
-        le = launch_tile_kernel(true, P, O, s);
+        le = launch_tile_kernel(1, P, O, s);
     }
     if (le == hipSuccess && nlong) le = launch_long_records(true, P, O, nlong, s);
     if (le != hipSuccess) {

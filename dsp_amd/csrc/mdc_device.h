@@ -62,7 +62,17 @@ enum : uint32_t {
     ST_NUMERIC_RANGE = 2u,
     ST_INTERNAL = 4u,
     ST_UNMAPPED = 8u,  // a tile of the sizing pass left no cell map: the write pass re-derives it
+    ST_OVERFLOW = 16u, // one-pass parse: an output array is smaller than what the input holds
+    ST_GIVEUP = 32u,   // one-pass parse: a tile waited too long for the tiles in front of it
 };
+
+// One-pass parse: what a tile publishes for the tiles behind it, one 64-bit word per counter (bytes of
+// every column, then rows), written with one store and read with one load: the kind in the two top
+// bits (0: nothing yet), the value below.  An aggregate is the tile's own count, an inclusive prefix
+// the count of the tile and of every tile in front of it.
+constexpr uint64_t PUB_AGG = 1ull << 62, PUB_INCL = 2ull << 62, PUB_VALUE = (1ull << 62) - 1;
+// status word 3 of a one-pass parse: tiles it left to the full write kernel
+constexpr uint32_t FUSED_SPIN_LIMIT = 1u << 16;  // polls before a tile gives up (the host then parses in two passes)
 
 struct DevCol {
     uint8_t name[32];
@@ -137,6 +147,9 @@ struct LdsLayout {
     uint32_t evcap;      // events per compaction window
     uint32_t stage_cap;  // = evcap*3
     uint32_t lbmax;      // look-behind capacity in bytes (multiple of 16)
+    uint32_t endl;       // one-pass parse: u16 [ncols][RB] end of every cell within its column's bytes of the tile
+    uint32_t tmpl;       // tagged input: event index per record, the template's column plan and its entries
+    uint32_t tmpl_bytes; // (the sizing pass keeps them in the space of the two row masks, which it does not use)
 };
 
 // A record longer than the look-behind of the tile that ends it (see long_record_kernel).
@@ -185,6 +198,10 @@ struct TileParams {
     uint32_t special_cols;       // the schema has time or binary32 columns (picks the write kernel's instance)
     uint32_t tmpl_sample;        // which record the template kernel samples: 0 = the second of the input, 1 = the third ...
     uint32_t debug;  // diagnostic builds only: phases to skip (ablation timing)
+    // one-pass parse
+    uint64_t *pub;          // [ncols+1][ntiles] published counts (PUB_*), zeroed before the launch
+    const uint64_t *caps;   // [ncols+1] what the output arrays hold: bytes per column, then rows
+    uint64_t *fused_totals; // [ncols+1] totals, written by the last tile (memory of the host)
 };
 
 // ------------------------------------------------------------------------------------------

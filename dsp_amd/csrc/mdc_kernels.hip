@@ -181,7 +181,14 @@ enum {
     MS_T0 = 11,     // long first record: LDS index of the first terminator of the tile
     MS_LONGE = 12,  // long first record: its entry in the list of long records
     MS_SEPOV = 13,  // delimited mode: two separator matches of the tile overlap
-    MS_COUNT = 16
+    MS_COUNT = 16,
+    // one-pass parse only (its layout has room for MS_XCOUNT words)
+    MS_ROW0 = 16,   // 2 words: the tile's first row
+    MS_STAGE = 18,  // bytes of the staging area handed out so far
+    MS_ODD = 19,    // the tile does not take the straight-line write: left to the full write kernel
+    MS_ROWOK = 20,  // the tile's rows fit the output arrays
+    MS_FWORD = 24,  // up to 4 words: found bits of a row that follows the template
+    MS_XCOUNT = 32
 };
 
 // unaligned LDS reads (gfx950 honours byte-unaligned ds_read_b64/b128)
@@ -1329,8 +1336,170 @@ __device__ __forceinline__ uint32_t column_cells(const CellEnv &E, const ColOut 
     return total;
 }
 
-template <bool WRITE>
-__global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const OutPtrs O) {
+// ---------------------------------------------------------------------------------------
+// One-pass parse: the sizing pass's analysis and the write in one kernel.  A tile cannot know where
+// its cells go before the tiles in front of it have counted theirs, so every tile publishes its counts
+// (bytes per column, rows) in one 64-bit word each and adds up what the tiles in front published:
+// a word is written by ONE store and read by ONE load of device scope, kind and value together, so it
+// needs no fence and no flag beside it.
+__device__ __forceinline__ void pub_store(uint64_t *p, uint64_t w) {
+    __hip_atomic_store((gmem_u64 *)p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t pub_load(const uint64_t *p) {
+    return __hip_atomic_load((const gmem_u64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The count of all tiles in front of `tile` for one counter (`pubj`: that counter's published words, one
+// per tile), by one wave: lane l looks at tile hi-1-l of the window [hi-64, hi).  The nearest inclusive
+// prefix that has every nearer tile's aggregate in front of it ends the search; a window of aggregates
+// only is added and the window moves on; a tile that has published nothing yet is waited for (the window
+// then begins at it).  Blocks start in index order on each of the chip's dispatchers, so the first tile
+// that has not finished is always resident and the wait ends; should it not, the tile gives up after
+// FUSED_SPIN_LIMIT polls (at once when another tile has given up) and the host parses the input in two passes.
+__device__ __forceinline__ uint64_t fused_lookback(const uint64_t *pubj, uint32_t tile, int lane, const uint32_t *status, bool &giveup) {
+    uint64_t excl = 0;
+    int64_t hi = (int64_t)tile;
+    uint32_t spins = 0;
+    while (hi > 0) {
+        const int64_t idx = hi - 1 - lane;
+        const uint64_t w = idx >= 0 ? pub_load(pubj + idx) : PUB_INCL;  // (in front of tile 0: an inclusive prefix of 0)
+        const uint32_t kind = (uint32_t)(w >> 62);
+        const uint64_t pm = __builtin_amdgcn_ballot_w64(kind != 0), im = __builtin_amdgcn_ballot_w64(kind == 2);
+        const uint32_t np = ~pm ? (uint32_t)__builtin_ctzll(~pm) : 64u;  // lanes [0, np) have published
+        const uint32_t fi = im ? (uint32_t)__builtin_ctzll(im) : 64u;   // the nearest inclusive prefix
+        const uint32_t take = fi < np ? fi : np;                          // aggregates of lanes [0, take)
+        const uint32_t agg = (uint32_t)lane < take ? (uint32_t)w : 0u;  // (a tile's own count fits 32 bits)
+        excl += wave_last(wave_incl_scan(agg));
+        if (fi < np) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, (int)fi);
+            const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), (int)fi);
+            return excl + ((((uint64_t)hi32 << 32) | lo) & PUB_VALUE);
+        }
+        hi -= take;
+        if (np < 64) {  // tile hi-1 has published nothing yet
+            // (once one tile has given up the result is dropped anyway: the others need not wait their turn out)
+            if (++spins > FUSED_SPIN_LIMIT ||
+                ((spins & 255u) == 0 && (__hip_atomic_load((const gmem_u32 *)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_GIVEUP))) {
+                giveup = true;
+                return excl;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    return excl;
+}
+
+// One column of a tile whose records all follow the tag template, by one wave: lane l has records l and
+// l + 64.  Only the straight-line cell routine (cell_simple) is there: false = some cell is not plain,
+// the column's type has no such routine, or the staging area is full, and the tile is left to the full
+// write kernel.  Values go to their rows at once (valp: this tile's first row of the column's values, or
+// null); the cells' bytes are ORed into a cleared piece of the staging area, 16 bytes behind the piece's
+// start `area_out`, and the end of every cell within the column's bytes of the tile goes to endl[record].
+template <bool SPECIAL>
+__device__ __forceinline__ bool fused_column(const CellEnv &E, uint32_t c, uint32_t typed, int lane, uint32_t RBn, gmem_u64 *valp,
+                                             const uint32_t (&cs_)[RB_PASSES], const uint32_t (&cl_)[RB_PASSES], uint32_t lvl,
+                                             bool found, uint16_t *endl, uint8_t *stage, uint32_t stage_cap, uint32_t *stage_top,
+                                             uint32_t &total_out, uint32_t &area_out) {
+    const uint32_t tyu = (uint32_t)__builtin_amdgcn_readfirstlane((int)typed);
+    if (tyu == T_BOOL || (!SPECIAL && (tyu == T_F32 || tyu == T_TIME))) return false;
+    const bool conv = tyu != T_NONE && (found || E.nulcut);
+    uint32_t cf_[RB_PASSES], cx_[RB_PASSES];
+    uint64_t clo_[RB_PASSES], chi_[RB_PASSES];
+    uint32_t total = 0;
+    bool ok = true;
+#pragma unroll
+    for (int ps = 0; ps < RB_PASSES; ++ps) {
+        const uint32_t r = ps * 64 + lane;
+        const bool act = r < RBn;
+        const uint4 w4 = lds_u128(E.sdata + cs_[ps]);  // (a lane without a record reads the image's first bytes)
+        const uint32_t lenp = act ? cl_[ps] : 0u;
+        uint32_t flen = 0;
+        uint64_t elo = 0, ehi = 0, value = 0;
+        bool valid = false;
+        const bool sc = SPECIAL && tyu == T_TIME
+                            ? cell_simple<false, true>(w4, lenp, lvl, tyu, conv, E.p10, E.tz_offset, flen, elo, ehi, value, valid)
+                        : SPECIAL && tyu == T_F32
+                            ? cell_simple<false, false, true>(w4, lenp, lvl, tyu, conv, E.p10, E.tz_offset, flen, elo, ehi, value, valid)
+                        : __builtin_amdgcn_ballot_w64(lenp > 8) == 0
+                            ? cell_simple<true>(w4, lenp, lvl, tyu, conv, E.p10, E.tz_offset, flen, elo, ehi, value, valid)
+                            : cell_simple<false>(w4, lenp, lvl, tyu, conv, E.p10, E.tz_offset, flen, elo, ehi, value, valid);
+        ok &= __builtin_amdgcn_ballot_w64(!sc) == 0;
+        if (!act) {
+            flen = 0;
+            valid = false;
+        }
+        if (act) {
+            if (valid) atomicOr(&E.vmask[r * E.W + (c >> 5)], 1u << (c & 31));
+            if (valp) valp[r] = value;
+        }
+        const uint32_t incl = wave_incl_scan(flen);
+        clo_[ps] = elo;
+        chi_[ps] = ehi;
+        cf_[ps] = flen;
+        cx_[ps] = total + incl - flen;
+        total += wave_last(incl);
+    }
+    if (!ok || total > 0xFFFFu) return false;
+    // a piece of the staging area: 16 bytes in front (the copy-out reads from the destination's 16-byte
+    // phase), the bytes, and what the word-wise ORs and reads may touch behind them
+    const uint32_t need = (16 + total + 20 + 15) & ~15u;
+    uint32_t top = 0;
+    if (lane == 0) top = atomicAdd(stage_top, need);
+    top = (uint32_t)__builtin_amdgcn_readfirstlane((int)top);
+    if (top + need > stage_cap) return false;
+    uint8_t *area = stage + top;
+    for (uint32_t u = lane; u < need / 16; u += 64) ((uint4 *)area)[u] = make_uint4(0, 0, 0, 0);
+    bool wide = false;
+#pragma unroll
+    for (int ps = 0; ps < RB_PASSES; ++ps) wide |= cf_[ps] > 8;
+    if (__builtin_amdgcn_ballot_w64(wide) == 0) {
+#pragma unroll
+        for (int ps = 0; ps < RB_PASSES; ++ps)
+            if (cf_[ps]) win_or<false>(area, 16 + cx_[ps], clo_[ps], chi_[ps], cf_[ps]);
+    } else {
+#pragma unroll
+        for (int ps = 0; ps < RB_PASSES; ++ps)
+            if (cf_[ps]) win_or<true>(area, 16 + cx_[ps], clo_[ps], chi_[ps], cf_[ps]);
+    }
+#pragma unroll
+    for (int ps = 0; ps < RB_PASSES; ++ps) {
+        const uint32_t r = ps * 64 + lane;
+        if (r < RBn) endl[r] = (uint16_t)(cx_[ps] + cf_[ps]);
+    }
+    total_out = total;
+    area_out = top;
+    return true;
+}
+
+// The staged bytes of one column of a tile (src: LDS, 16-byte aligned) to their place in the column's
+// arena, which is known by now: 16-byte stores at the destination's phase, the LDS side read as aligned
+// words shifted into place.
+__device__ __forceinline__ void fused_copy_out(const uint8_t *src, uint32_t total, gmem_u8 *dst, int lane) {
+    uint32_t head = (16 - (uint32_t)((size_t)dst & 15)) & 15;
+    if (head > total) head = total;
+    if ((uint32_t)lane < head) dst[lane] = src[lane];
+    const uint32_t body = (total - head) / 16;
+    for (uint32_t u = lane; u < body; u += 64) {
+        const uint4 v = lds_bytes16(src + head + u * 16);
+        u32x4 o;
+        o[0] = v.x;
+        o[1] = v.y;
+        o[2] = v.z;
+        o[3] = v.w;
+        *(gmem_u128 *)(dst + head + u * 16) = o;
+    }
+    const uint32_t done = head + body * 16;
+    if ((uint32_t)lane < total - done) dst[done + lane] = src[done + lane];
+}
+
+// MODE: the sizing pass, the full write pass, or the one-pass parse (the sizing pass's analysis, then for a
+// tile whose records all follow the tag template the straight-line write; output places come from the
+// tiles in front through published counts, see fused_* above).
+enum : int { PASS_SIZING = 0, PASS_WRITE = 1, PASS_FUSED = 2, PASS_FUSED_SPECIAL = 3 };  // (SPECIAL: see column_cells)
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void tile_kernel(const TileParams P, const OutPtrs O) {
+    constexpr bool WRITE = MODE == PASS_WRITE;
+    constexpr bool FUSED = MODE == PASS_FUSED || MODE == PASS_FUSED_SPECIAL;
     extern __shared__ __align__(16) uint8_t smem[];
     const LdsLayout &L = P.L;
     uint8_t *sdata = smem + L.data;
@@ -1368,13 +1537,12 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
 
     // event index at the start of every record of the batch (entry 0: minus the events of the
     // tile's first record that lie in the look-behind), then the template's entries
-    int16_t *e0t = (int16_t *)(smem + L.vmask);
+    int16_t *e0t = (int16_t *)(smem + L.tmpl);
     const uint32_t e0_bytes = ((L.RB + 2) * 2 + 15) & ~15u;
     const uint32_t plan_bytes = (P.ncols * 8 + 15) & ~15u;
-    uint2 *plan_l = (uint2 *)(smem + L.vmask + e0_bytes);  // the template's column plan
-    uint4 *tmpl_l = (uint4 *)(smem + L.vmask + e0_bytes + plan_bytes);
-    const uint32_t tmpl_room =
-        L.coltot - L.vmask > e0_bytes + plan_bytes ? (L.coltot - L.vmask - e0_bytes - plan_bytes) / 16 : 0;
+    uint2 *plan_l = (uint2 *)(smem + L.tmpl + e0_bytes);  // the template's column plan
+    uint4 *tmpl_l = (uint4 *)(smem + L.tmpl + e0_bytes + plan_bytes);
+    const uint32_t tmpl_room = L.tmpl_bytes > e0_bytes + plan_bytes ? (L.tmpl_bytes - e0_bytes - plan_bytes) / 16 : 0;
     const uint32_t tmpl_cap = tmpl_room < TMPL_MAX ? tmpl_room : TMPL_MAX;
     const uint32_t nT_in = P.tmpl[0];
 
@@ -1417,11 +1585,12 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
         for (int k = 0; k < 4; ++k) ((uint4 *)sdata)[ts_li / CHUNK + k * BLOCK + tid] = tv[k];
         if (lbmine) ((uint4 *)sdata)[jlb] = lbv;
         if ((uint32_t)tid < sch16) s[tid] = sv;
-        if (!WRITE && P.use_tmpl && tid >= 1 && (uint32_t)tid <= tmpl_cap) tmpl_l[tid - 1] = tq;
-        if (!WRITE && P.use_tmpl && tmpl_room && (uint32_t)tid > TMPL_MAX && (uint32_t)tid <= TMPL_MAX + plan16)
+        if (P.use_tmpl && tid >= 1 && (uint32_t)tid <= tmpl_cap) tmpl_l[tid - 1] = tq;
+        if (P.use_tmpl && tmpl_room && (uint32_t)tid > TMPL_MAX && (uint32_t)tid <= TMPL_MAX + plan16)
             ((uint4 *)plan_l)[tid - 1 - TMPL_MAX] = tq;
         for (uint32_t i = tid + BLOCK; i < sch16; i += BLOCK) s[i] = g[i];
         if (tid < MS_COUNT) ms[tid] = tid == MS_LAST ? NONE : 0;
+        if (FUSED && tid >= MS_COUNT && tid < MS_XCOUNT) ms[tid] = 0;
     }
     __syncthreads();
     const SchemaHdr *H = (const SchemaHdr *)(smem + L.schema);
@@ -1434,13 +1603,13 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
     // events and the field descriptors are made in parallel (otherwise: one lane walks each record)
     const bool sepfast = csv && !WRITE && H->sep_fast;
     // tagged input, sizing pass: records that repeat the sample record's tags take the template
-    const bool tmode = !WRITE && !csv && P.use_tmpl && nT_in != 0 && nT_in <= tmpl_cap;
+    const bool tmode = !csv && P.use_tmpl && nT_in != 0 && nT_in <= tmpl_cap;
     const uint32_t nT = nT_in;
     uint32_t *coltot = (uint32_t *)(smem + L.coltot);  // write pass: the sizing pass's bytes per column of this tile
     uint32_t *tiletot = coltot + (ncols + 1);          // totals of the batches done so far
     for (uint32_t c = tid; c < ncols + 1; c += BLOCK) tiletot[c] = 0;
     STAMP(0);  // loads
-    if (!WRITE && SKIP(8)) return;  // (diagnostic builds: the kernel up to here)
+    if (MODE == PASS_SIZING && SKIP(8)) return;  // (diagnostic builds: the kernel up to here)
 
     // searches the staged chunks [lo, hi) for record terminators; keeps the last one
     auto search_terminators = [&](int lo_li, int hi_li) {
@@ -1550,6 +1719,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
     };
     rank_scan();
     const uint32_t nrec_all = nrec;  // records the tile owns (one more than it goes through when the first is a long one)
+    // one-pass parse: the tiles behind learn this tile's rows as early as they are known
+    if (FUSED && tid == 0) pub_store(P.pub + (uint64_t)ncols * P.ntiles + blockIdx.x, PUB_AGG | nrec_all);
     // start of the first owned record: behind the last terminator in front of the tile (a tile
     // that ends no record owns none and has nothing to look for)
     int s0_li = ts_li;
@@ -1649,7 +1820,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
             if (longrec) tiletot[c] = P.long_len[(uint64_t)long_entry * ncols + c];  // bytes the long record's cells take
         }
     }
-    if (WRITE && blockIdx.x == 0) {
+    if ((WRITE || FUSED) && blockIdx.x == 0) {
         if (tid == 0 && P.rec_off) P.rec_off[0] = 0;
         for (uint32_t c = tid; c < ncols; c += BLOCK) O.off[c][0] = 0;
     }
@@ -1689,13 +1860,42 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
         }
     }
     STAMP(1);  // classify + rank scan
-    if (!WRITE && SKIP(4)) return;  // (diagnostic builds: the kernel up to here)
+    if (MODE == PASS_SIZING && SKIP(4)) return;  // (diagnostic builds: the kernel up to here)
+
+    // one-pass parse: a tile takes the straight-line write when all its records follow the template, fit
+    // one batch and no text cell may need the NUL cut; its first row comes from the tiles in front
+    const bool fz_try = FUSED && tmode && !longrec && nrec <= RB && !(carry && !csv && has_nul);
+    bool fz = false;         // (block-uniform) the tile has taken it
+    bool rows_done = false;  // (block-uniform) the rows in front of the tile have been added up
+    auto rows_lookback = [&]() {
+        if (FUSED && !rows_done && wave == BLOCK / 64 - 1) {
+            bool gu = false;
+            uint64_t *pr = P.pub + (uint64_t)ncols * P.ntiles;
+            const uint64_t r0 = SKIP(2048) ? (uint64_t)blockIdx.x * 90 : fused_lookback(pr, blockIdx.x, lane, P.status, gu);
+            if (lane == 0) {
+                pub_store(pr + blockIdx.x, PUB_INCL | (r0 + nrec_all));
+                const bool fits = r0 + nrec_all <= P.caps[ncols];
+                ms[MS_ROW0] = (uint32_t)r0;
+                ms[MS_ROW0 + 1] = (uint32_t)(r0 >> 32);
+                ms[MS_ROWOK] = fits && !gu ? 1u : 0u;
+                if (gu) raise_status(P, ST_GIVEUP);
+                if (!fits) raise_status(P, ST_OVERFLOW);
+                if (blockIdx.x == P.ntiles - 1) P.fused_totals[ncols] = r0 + nrec_all;
+            }
+        }
+        rows_done = true;
+    };
+    if (FUSED && tmode && (uint32_t)tid < W) {  // found bits of a row that follows the template: the plan's
+        uint32_t word = 0;
+        for (uint32_t c = tid * 32; c < ncols && c < (uint32_t)tid * 32 + 32; ++c) word |= ((plan_l[c].x >> 10) & 1u) << (c & 31);
+        ms[MS_FWORD + tid] = word;
+    }
 
     // ---- batches of RB records
     for (uint32_t rb0 = 0; rb0 < nrec; rb0 += RB) {
         const uint32_t RBn = (nrec - rb0 < RB) ? nrec - rb0 : RB;
         for (uint32_t i = tid; i < (RB * npat + 1) / 2; i += BLOCK) evt[i] = NONE;
-        if (WRITE)  // (the sizing pass keeps the tag template there; its delimited walk stores whole words)
+        if (WRITE || FUSED)  // (the sizing pass keeps the tag template there; its delimited walk stores whole words)
             for (uint32_t i = tid; i < RB * W; i += BLOCK) {
                 vmask[i] = 0;
                 fmask[i] = 0;
@@ -1758,6 +1958,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
                 walk((uint32_t)(em >> 32), (uint32_t)(tm >> 32), (uint32_t)my_li + 32);
             }
             if (!ok) ms[MS_IRR] = 1;
+            rows_lookback();
             __syncthreads();
             irregular = ms[MS_IRR] != 0;  // (nobody writes the flag again before the next barrier)
             general = irregular;
@@ -1791,6 +1992,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
                     if (r >= rb0 && r < rb0 + RBn) match_tag(sdata, H, cols, ht, (uint32_t)(my_li + b), evt, r - rb0, RB);
                 }
             }
+            rows_lookback();
             __syncthreads();
         }
         STAMP(3);  // events
@@ -1925,7 +2127,71 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
                 len = (uint32_t)l;
             }
         };
-        if (!WRITE && fastcsv) {
+        // One-pass parse, a tile that follows the template: the straight-line write, one wave per column.
+        // Values go to their rows, the cells' bytes to the staging area; a wave that meets a cell which is
+        // not plain raises MS_ODD and the tile is measured below like any other.
+        bool fzb = FUSED && fz_try && !irregular;
+        if (FUSED && fzb) {
+            const uint64_t frow0 = (uint64_t)ms[MS_ROW0] | ((uint64_t)ms[MS_ROW0 + 1] << 32);
+            const bool rowok = ms[MS_ROWOK] != 0;
+            uint16_t *endl = (uint16_t *)(smem + L.endl);
+            for (uint32_t c = wave; c < ncols; c += BLOCK / 64) {
+                const uint32_t typed = (uint32_t)__builtin_amdgcn_readfirstlane((int)cols[c].typed);
+                const uint2 pl = plan_l[c];
+                const uint32_t cs = pl.x & 0xFFu, nml2 = pl.x >> 16, lvl = (pl.x >> 8) & 3u;
+                const int cl = (int)pl.y;
+                const bool found = (pl.x >> 10) & 1u, hassrc = (pl.x >> 11) & 1u;
+                uint32_t cs_[RB_PASSES], cl_[RB_PASSES];
+#pragma unroll
+                for (int ps = 0; ps < RB_PASSES; ++ps) {
+                    const uint32_t r = ps * 64 + lane;
+                    uint32_t s = 0, len = 0;
+                    if (r < RBn) {
+                        const uint32_t o = ((const uint16_t *)evt)[(2 * cs) * RB + r], e = ((const uint16_t *)evt)[(2 * cs + 1) * RB + r];
+                        const uint32_t re = recend[r + 1];
+                        const uint32_t s1 = o + nml2;
+                        int l = (int)e - (int)s1;
+                        l = l < 0 ? (int)(re - s1) : (cl > 0 && cl < l) ? cl : l;
+                        const bool have = hassrc & (o != NONE16) & (e != NONE16);
+                        s = have ? s1 : 0u;
+                        len = have ? (uint32_t)l : 0u;
+                    }
+                    cs_[ps] = s;
+                    cl_[ps] = len;
+                }
+                gmem_u64 *valp = (typed != T_NONE && rowok) ? (gmem_u64 *)O.val[c] + frow0 : nullptr;
+                uint32_t total = 0, area = 0;
+                const bool ok = fused_column<MODE == PASS_FUSED_SPECIAL>(E, c, typed, lane, RBn, valp, cs_, cl_, lvl, found, endl + c * RB,
+                                                                         stage, L.stage_cap, &ms[MS_STAGE], total, area);
+                if (!ok) {
+                    if (lane == 0) ms[MS_ODD] = 1;
+                    break;
+                }
+                if (lane == 0) {
+                    tiletot[c] = total;
+                    coltot[c] = area;  // (the sizing pass has no use for this half of the array)
+                }
+            }
+            __syncthreads();
+            if (ms[MS_ODD]) {  // measured again, the general way
+                fzb = false;
+                for (uint32_t c = tid; c < ncols + 1; c += BLOCK) tiletot[c] = 0;
+                __syncthreads();
+            } else {
+                fz = true;
+                if ((uint32_t)tid < RBn && rowok) {
+                    const uint64_t row = frow0 + tid;
+                    if (P.rec_off) P.rec_off[row + 1] = (uint64_t)(base_pos + (int64_t)recend[tid + 1] + 1);
+#pragma unroll 1
+                    for (uint32_t w = 0; w < W; ++w) {
+                        P.valid[row * W + w] = vmask[tid * W + w];
+                        P.found[row * W + w] = ms[MS_FWORD + w];
+                    }
+                }
+            }
+        }
+        if (fzb) {
+        } else if (!WRITE && fastcsv) {
             // Delimited input whose separators were collected: one lane per (field, record).  Field c
             // lies between the record's separators c-1 and c; a field is text, so its length is all the
             // sizing pass needs (no descriptor in LDS, no second loop).  Only a first record that starts
@@ -2123,7 +2389,25 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
                 uint32_t s = 0, len = 0, lvl = LVL_CHAR;
                 bool found = false;
                 if (r < RBn) {
-                    fetch_cell(c, r, s, len, lvl, found);
+                    if (tmode && !irregular) {
+                        // every record of the tile has the sample's tags: which column a cell comes
+                        // from, its level and the clip are the plan's, only the positions are the record's
+                        const uint2 pl = plan_l[c];
+                        const uint32_t cs = pl.x & 0xFFu, nml2 = pl.x >> 16;
+                        const int cl = (int)pl.y;
+                        lvl = (pl.x >> 8) & 3u;
+                        found = (pl.x >> 10) & 1u;
+                        const uint32_t o = ((const uint16_t *)evt)[(2 * cs) * RB + r], e = ((const uint16_t *)evt)[(2 * cs + 1) * RB + r];
+                        const uint32_t re = recend[r + 1];
+                        s = o + nml2;
+                        int l = (int)e - (int)s;
+                        l = l < 0 ? (int)(re - s) : (cl > 0 && cl < l) ? cl : l;
+                        const bool have = ((pl.x >> 11) & 1u) & (o != NONE16) & (e != NONE16);
+                        s = have ? s : 0u;
+                        len = have ? (uint32_t)l : 0u;
+                    } else {
+                        fetch_cell(c, r, s, len, lvl, found);
+                    }
                     if (found && !csv) atomicOr(&fmask[r * W + (c >> 5)], 1u << (c & 31));
                 }
                 cs_[ps] = s;
@@ -2168,20 +2452,62 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
         for (uint32_t c = tid; c < ncols; c += BLOCK)
             if (tiletot[c] != coltot[c]) raise_status(P, ST_INTERNAL);
     }
+    bool odd = false;  // one-pass parse: (block-uniform) the tile is left to the full write kernel
+    if (FUSED) {
+        // (tiles that went through no tag search: tiles without records, delimited input)
+        rows_lookback();
+        __syncthreads();  // the tile's counts, its first row and its staging pieces are final
+        odd = !fz;
+        const uint32_t tile = blockIdx.x;
+        // what this tile counted, for the tiles behind ...
+        for (uint32_t c = tid; c < ncols; c += BLOCK) pub_store(P.pub + (uint64_t)c * P.ntiles + tile, PUB_AGG | tiletot[c]);
+        // ... then, one wave per column, what the tiles in front counted: the column's place in its arena
+        const uint64_t frow0 = (uint64_t)ms[MS_ROW0] | ((uint64_t)ms[MS_ROW0 + 1] << 32);
+        const bool rowok = ms[MS_ROWOK] != 0;
+        const uint16_t *endl = (const uint16_t *)(smem + L.endl);
+        uint64_t *tbw = const_cast<uint64_t *>(P.tile_base) + (uint64_t)tile * (ncols + 1);
+        for (uint32_t c = wave; c < ncols; c += BLOCK / 64) {
+            bool gu = false;
+            uint64_t *pc = P.pub + (uint64_t)c * P.ntiles;
+            const uint64_t base = SKIP(1024) ? (uint64_t)tile * (tiletot[c] - tiletot[c] / 8) : fused_lookback(pc, tile, lane, P.status, gu);
+            const uint32_t tot = tiletot[c];
+            const bool fits = base + tot <= P.caps[c];
+            if (lane == 0) {
+                pub_store(pc + tile, PUB_INCL | (base + tot));
+                if (gu) raise_status(P, ST_GIVEUP);
+                if (!fits) raise_status(P, ST_OVERFLOW);
+                if (tile == P.ntiles - 1) P.fused_totals[c] = base + tot;
+                if (odd) tbw[c] = base;
+            }
+            if (!odd && fits && rowok && !gu) {
+                fused_copy_out(stage + coltot[c] + 16, tot, (gmem_u8 *)O.bytes[c] + base, lane);
+                gmem_u32 *offp = (gmem_u32 *)O.off[c] + frow0 + 1;
+#pragma unroll
+                for (int ps = 0; ps < RB_PASSES; ++ps) {
+                    const uint32_t r = ps * 64 + lane;
+                    if (r < nrec) offp[r] = (uint32_t)(base + endl[c * RB + r]);
+                }
+            }
+        }
+        if (tid == 0 && odd) {
+            tbw[ncols] = frow0;
+            atomicAdd(P.status + 3, 1u);
+        }
+    }
     if (!WRITE) {
         if (tmode && irregular && tid == 0) atomicAdd(P.status + 1, 1u);  // the host renews a template few tiles follow
-        uint32_t *tc = P.tile_counts + (uint64_t)blockIdx.x * (ncols + 1);
-        for (uint32_t c = tid; c < ncols; c += BLOCK) tc[c] = tiletot[c];
-        if (tid == 0) {
-            tc[ncols] = nrec_all;
-            if (P.tile_hdr) {
-                // all batches are done (a barrier follows the last batch's cells): is the tile's map complete?
-                const uint32_t slot = map_slot;
-                const bool mapped = slot != NONE && !ms[MS_NOMAP];
-                P.tile_hdr[2 * blockIdx.x] = mapped ? slot : longrec ? HDR_LONGREC : NONE;
-                P.tile_hdr[2 * blockIdx.x + 1] = longrec ? long_entry : (uint32_t)s0_li | (has_nul ? 0x80000000u : 0u);
-                if (!mapped) atomicOr(P.status, ST_UNMAPPED);
-            }
+        if (!FUSED || odd) {
+            uint32_t *tc = P.tile_counts + (uint64_t)blockIdx.x * (ncols + 1);
+            for (uint32_t c = tid; c < ncols; c += BLOCK) tc[c] = tiletot[c];
+            if (tid == 0) tc[ncols] = nrec_all;
+        }
+        if (tid == 0 && P.tile_hdr) {
+            // all batches are done (a barrier follows the last batch's cells): is the tile's map complete?
+            const uint32_t slot = map_slot;
+            const bool mapped = FUSED ? !odd : (slot != NONE && !ms[MS_NOMAP]);
+            P.tile_hdr[2 * blockIdx.x] = mapped ? (FUSED ? 0u : slot) : longrec ? HDR_LONGREC : NONE;
+            P.tile_hdr[2 * blockIdx.x + 1] = longrec ? long_entry : (uint32_t)s0_li | (has_nul ? 0x80000000u : 0u);
+            if (!mapped) raise_status(P, ST_UNMAPPED);
         }
     }
 }
@@ -2189,7 +2515,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileParams P, const O
 // Write pass over tiles whose cell map the sizing pass completed: no record split, no tag
 // search.  A block loads its tile (and the head of its first record from the look-behind),
 // rebuilds the digit bitmap, reads each cell's source from the map and runs the same column
-// routine as the tile kernel.  Tiles without a map are left to tile_kernel<true>.
+// routine as the tile kernel.  Tiles without a map are left to the full write pass of the tile kernel.
 // MANY: the instance for inputs whose tiles take several batches (batches of a multiple of 64 records):
 // later batches' map words come straight into LDS, see below.
 template <bool SPECIAL, bool MANY>
@@ -2946,20 +3272,21 @@ hipError_t launch_template_kernel(const TileParams &P, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_tile_kernel(bool write, const TileParams &P, const OutPtrs &O, hipStream_t stream) {
+// mode: 0 = sizing pass, 1 = full write pass, 2 = one-pass parse
+hipError_t launch_tile_kernel(int mode, const TileParams &P, const OutPtrs &O, hipStream_t stream) {
     if (P.ntiles == 0) return hipSuccess;
+    void (*const fn)(const TileParams, const OutPtrs) = mode == 0   ? tile_kernel<PASS_SIZING>
+                                                        : mode == 1 ? tile_kernel<PASS_WRITE>
+                                                        : P.special_cols ? tile_kernel<PASS_FUSED_SPECIAL>
+                                                                         : tile_kernel<PASS_FUSED>;
     // per device and cheap: set on every launch so that each GPU of a process gets it
-    const void *fn = write ? (const void *)tile_kernel<true> : (const void *)tile_kernel<false>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     uint32_t lds = P.L.total;
 #ifdef MDC_ABLATE
     if (const char *e = getenv("MDC_DEBUG_LDS")) lds = (uint32_t)atoi(e);  // occupancy experiments
 #endif
-    if (write)
-        hipLaunchKernelGGL(tile_kernel<true>, dim3(P.ntiles), dim3(BLOCK), lds, stream, P, O);
-    else
-        hipLaunchKernelGGL(tile_kernel<false>, dim3(P.ntiles), dim3(BLOCK), lds, stream, P, O);
+    hipLaunchKernelGGL(fn, dim3(P.ntiles), dim3(BLOCK), lds, stream, P, O);
     return hipGetLastError();
 }
 

@@ -92,7 +92,12 @@ typedef struct mdc_opts {
 } mdc_opts;
 
 enum {
-    MDC_F_NO_RECOFF = 1u  /* do not materialise the record-offset array                     */
+    MDC_F_NO_RECOFF = 1u, /* do not materialise the record-offset array                     */
+    MDC_F_ONE_PASS = 2u   /* tagged input, from the parser's second parse on: size and write in ONE kernel.  The */
+                          /* output arrays are sized from the previous parse with a margin and every tile      */
+                          /* learns its place from the tiles in front of it inside the launch; an input that    */
+                          /* does not fit is parsed again in two passes.  Same results; measured slower than    */
+                          /* the two passes (2.2 ms against 1.4 ms for 1 GiB), so it is off unless asked for    */
 };
 
 typedef struct mdc_parser mdc_parser;
@@ -112,6 +117,9 @@ typedef struct mdc_timing {
     int lookup_tiles; /* tagged input: tiles whose records did not all repeat the sampled record's tags */
                       /* and took the tag table instead (0 for delimited input)                         */
     int long_records; /* records longer than the look-behind window, parsed by the long-record kernel */
+    int one_pass;     /* 1 = sizing and writing were one kernel (MDC_F_ONE_PASS); count_ms and scan_ms are 0 */
+    int one_pass_redone; /* 1 = a one-pass parse was given up (an output array too small, a long record) and   */
+                         /* the input parsed again in two passes: total_ms covers the second parse only         */
 } mdc_timing;
 
 /* ---- library ------------------------------------------------------------------------ */
