@@ -42,7 +42,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from dsp_amd import archive, capi, gen, schema  # noqa: E402  (nothing here touches the GPU at import)
+from dsp_amd import archive, capi, gen, schema, shard  # noqa: E402  (nothing here touches the GPU at import)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec
 
@@ -73,8 +73,9 @@ def parse_args():
 # N > 1 without a launcher: this process only starts the ranks
 
 def launch_ranks(a):
-    """Starts a.gpus rank processes of this script (one GPU each through LOCAL_RANK) and passes
-    rank 0's line through.  Called before anything in this process has touched the GPU."""
+    """Starts a.gpus rank processes of this script and passes rank 0's line through.  Called before
+    anything in this process has touched the GPU.  Every rank narrows itself to one GPU and a CPU set of
+    its own when it starts (shard.isolate_rank in main), as it does under an external launcher."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -286,7 +287,7 @@ def verify_prefix(parser, dbuf, data, workload):
     return int(n)
 
 
-def archive_section(a, parser, rank, world, barrier, reduce_sum, reduce_max, files):
+def archive_section(a, parser, rank, world, barrier, reduce_sum, reduce_max, gather, files):
     """Every rank has written the files of its share (deterministic: file i is the same bytes
     whoever writes it); all ranks stream their shares between two barriers."""
     nfiles = a.archive_files_per_gpu * world
@@ -303,12 +304,16 @@ def archive_section(a, parser, rank, world, barrier, reduce_sum, reduce_max, fil
         raise SystemExit(f"archive share of rank {rank}: rows per file differ from the generator's ({res.errors[:2]})")
     tot = reduce_sum([float(res.rows), float(sum(nbytes)), float(len(paths))])
     slowest = reduce_max(res.seconds)
+    per_rank = gather(round(sum(nbytes) / res.seconds / 1e9, 3))
     return {
         "workload": f"{nfiles} files of {a.archive_file_mb} MiB ZHOBTMIND XML in sorted order, dealt round-robin to {world} rank(s), "
                     "each share through mdc_stream (page cache -> pinned -> HBM -> columns)",
         "files": int(tot[2]), "bytes": int(tot[1]), "rows": int(tot[0]), "rows_match_generator": True,
         "threads_per_rank": a.archive_threads, "seconds": round(slowest, 4),
         "GBps_end_to_end": round(tot[1] / slowest / 1e9, 3), "records_per_s": round(tot[0] / slowest, 1),
+        "per_rank_GBps": per_rank,
+        "note": "the file-sharded figure (GBps_end_to_end over 1/2/4/8 ranks) is the scaling metric of the archive configuration; "
+                "it is bound by the host (page-cache reads into pinned memory), not by the GPUs",
     }
 
 
@@ -368,7 +373,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    iso = {"gpu": None, "cpus": shard.format_cpulist(sorted(os.sched_getaffinity(0)))}
     if world > 1:
+        # one GPU and a CPU set of its own per rank, before anything touches the runtime: the rank's
+        # device 0 is then its GPU, and the threads it starts later (readers, uploads) stay on its cores
+        iso = shard.isolate_rank(local_rank, world)
         import torch
         import torch.distributed as dist  # gloo on host tensors only: timings and row counts
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -390,7 +399,7 @@ def main():
     ndev = capi.lib().mdc_device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU: the parsing path exists only as gfx950 code")
-    device = local_rank % ndev
+    device = local_rank % ndev  # (0 for a rank that was narrowed to its own GPU)
 
     def reduce_sum(vals):
         if dist is None:
@@ -406,6 +415,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0])
 
+    def gather(obj):
+        """Every rank's object, in rank order (host objects over gloo)."""
+        if dist is None:
+            return [obj]
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+
     data, rows_gen = make_data(a.workload, a.bytes, rank)
     parser = make_parser(a.workload, device)
     dbuf = capi.DeviceBuffer(data, device)
@@ -419,10 +436,11 @@ def main():
     local_s, acc, rows, bytes_out = timed_steps(parser, dbuf, a.steps, a.warmup, barrier)
     elapsed = reduce_max(local_s)
     total_bytes, total_rows = reduce_sum([float(dbuf.n), float(rows)])
+    ranks = gather({"rank": rank, "gpu": iso["gpu"], "device": device, "cpus": iso["cpus"]})
 
     arch = e2e = None
     if arch_files is not None:
-        arch = archive_section(a, parser, rank, world, barrier, reduce_sum, reduce_max, arch_files)
+        arch = archive_section(a, parser, rank, world, barrier, reduce_sum, reduce_max, gather, arch_files)
         if gz_files is not None:
             e2e = e2e_section(a, parser, data, gz_files)
         if own_dir:
@@ -456,6 +474,7 @@ def main():
                 "bytes_per_gpu": dbuf.n, "records_per_gpu": rows, "sharding": "one batch per GPU, no collective",
             },
             "records_per_s": round(total_rows * k / elapsed, 1),
+            "ranks": ranks,
             "roofline": roofline_of("mdc::emit_kernel (write pass)", dbuf.n, bytes_out, write_ms,
                                     measured_traffic("mdc::emit_kernel", dbuf.n) if a.workload == "xml" else None),
             "kernel_ms": {"sizing_pass": round(acc["count"] / k, 4), "scan": round(acc["scan"] / k, 4),

@@ -60,4 +60,10 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     assert out["config"]["bytes_per_gpu"] > 30 << 20
     assert out["archive"]["files"] == 4 and out["archive"]["rows_match_generator"]
-    assert out["archive"]["GBps_end_to_end"] > 0
+    assert out["archive"]["GBps_end_to_end"] > 0 and len(out["archive"]["per_rank_GBps"]) == 2
+    # every rank was narrowed to one GPU (both to this box's only one) and to cores of its own
+    from dsp_amd import shard
+    ranks = out["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["device"] == 0 for r in ranks)
+    cpus = [set(shard.parse_cpulist(r["cpus"])) for r in ranks]
+    assert cpus[0] and cpus[1] and not cpus[0] & cpus[1]

@@ -123,3 +123,83 @@ def test_archive_shares_are_a_partition_in_sorted_order(tmp_path):
     gz = archive.make_files(str(tmp_path / "c"), [3], 1 << 16, gz=True, workers=1)
     import gzip
     assert gzip.decompress(open(gz[0][0], "rb").read()) == open(a[0][0], "rb").read()
+
+
+# ---- one process per GPU: which GPU a rank sees, which cores it runs on (host logic, no GPU needed)
+
+def _fake_sysfs(root, gpus):
+    """A KFD topology with one CPU node and the given GPUs [(bus, numa node)], and two NUMA nodes of 8 cores."""
+    nodes = root / "class/kfd/kfd/topology/nodes"
+    (nodes / "0").mkdir(parents=True)
+    (nodes / "0" / "properties").write_text("cpu_cores_count 16\nsimd_count 0\n")
+    for i, (bus, numa) in enumerate(gpus):
+        d = nodes / str(i + 1)
+        d.mkdir()
+        d.joinpath("properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {bus << 8}\ndomain 0\n")
+        pci = root / "bus/pci/devices" / ("0000:%02x:00.0" % bus)
+        pci.mkdir(parents=True)
+        pci.joinpath("numa_node").write_text(f"{numa}\n")
+    for n in (0, 1):
+        d = root / f"devices/system/node/node{n}"
+        d.mkdir(parents=True)
+        d.joinpath("cpulist").write_text(f"{8 * n}-{8 * n + 7}\n")
+
+
+def test_cpulist_round_trip():
+    assert shard.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert shard.format_cpulist([11, 0, 1, 2, 3, 8, 10]) == "0-3,8,10-11"
+    assert shard.parse_cpulist("") == [] and shard.format_cpulist([]) == ""
+
+
+def test_gpu_numa_nodes_from_the_kfd_topology(tmp_path):
+    _fake_sysfs(tmp_path, [(0x05, 0), (0x15, 0), (0x85, 1), (0x95, 1)])
+    assert shard.gpu_numa_nodes(str(tmp_path)) == [0, 0, 1, 1]
+    assert shard.count_gpus(str(tmp_path)) == 4
+    assert shard.gpu_numa_nodes(str(tmp_path / "nothing_here")) is None
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_rank_cpu_sets_are_disjoint_and_follow_the_numa_nodes(world):
+    avail = list(range(128))
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    node_cpus = {0: list(range(64)), 1: list(range(64, 128))}
+    sets = shard.rank_cpu_sets(world, avail, nodes, node_cpus)
+    assert len(sets) == world and all(sets)
+    flat = [c for s in sets for c in s]
+    assert len(flat) == len(set(flat))  # disjoint
+    for r, s in enumerate(sets):
+        assert set(s) <= set(node_cpus[nodes[r]])  # on the GPU's own node
+    # no topology: an even split of what the process may use
+    even = shard.rank_cpu_sets(world, range(16))
+    assert [len(s) for s in even] == [16 // world] * world
+    assert len({c for s in even for c in s}) == 16
+    # two ranks on one GPU divide that GPU's node
+    two = shard.rank_cpu_sets(2, range(16), [0], {0: list(range(16))}, gpus=[0, 0])
+    assert two == [list(range(8)), list(range(8, 16))]
+
+
+def _isolated(local_rank, world, sysfs, q):
+    os.environ.pop("ROCR_VISIBLE_DEVICES", None)
+    os.environ.pop("HIP_VISIBLE_DEVICES", None)
+    got = shard.isolate_rank(local_rank, world, sysfs=sysfs)
+    q.put((local_rank, got, os.environ.get("ROCR_VISIBLE_DEVICES"), sorted(os.sched_getaffinity(0))))
+
+
+def test_isolate_rank_sets_the_gpu_and_the_affinity(tmp_path):
+    avail = sorted(os.sched_getaffinity(0))
+    if len(avail) < 2:
+        pytest.skip("needs two cores")
+    _fake_sysfs(tmp_path, [(0x05, 0), (0x85, 0)])
+    # (the fake nodes name cores 0-15; whatever of them this process may use is divided)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_isolated, args=(r, 2, str(tmp_path), q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=60) for _ in ps)
+    for p in ps:
+        p.join()
+    (r0, g0, env0, aff0), (r1, g1, env1, aff1) = got
+    assert (env0, env1) == ("0", "1") and (g0["gpu"], g1["gpu"]) == ("0", "1")
+    assert aff0 and aff1 and not set(aff0) & set(aff1)
+    assert shard.parse_cpulist(g0["cpus"]) == aff0 and shard.parse_cpulist(g1["cpus"]) == aff1
