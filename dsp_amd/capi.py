@@ -30,6 +30,7 @@ MDC_ERR_TOO_LARGE = -6
 MDC_ERR_NUMERIC = -7
 MDC_ERR_IO = -8
 MDC_ERR_INTERNAL = -9
+MDC_ERR_BUSY = -10
 MDC_F_NO_RECOFF = 1
 MDC_F_ONE_PASS = 2
 

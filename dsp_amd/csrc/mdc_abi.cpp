@@ -15,6 +15,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -93,6 +94,8 @@ struct Device {
     hipStream_t up_stream[UPLOAD_THREADS] = {};     // created on the first large host buffer
     hipEvent_t up_event[2 * UPLOAD_THREADS] = {};
     std::mutex up_mu;  // one staged upload at a time per device (they would share the link anyway)
+    std::mutex noalloc_mu;  // one call at a time per device in the static scratch array of mdc_parse_device_noalloc
+    bool scratch_ready = false;  // (under noalloc_mu) the array's address on this device has been looked up
     std::mutex mu;
     std::multimap<size_t, void *> free_blocks;
     std::map<void *, size_t> live;
@@ -118,10 +121,11 @@ static int get_device(int id, Device **out) {
     HIP_TRY(hipSetDevice(id));
     Device *d = new Device();
     d->id = id;
-    HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-    // this device's copy of the static scratch array (mdc_parse_device_noalloc): its address is
-    // looked up here, once, while the device is current
-    HIP_TRY(noalloc_scratch_init(id));
+    const hipError_t se = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        delete d;
+        return fail(MDC_ERR_HIP, "hipStreamCreateWithFlags: %s", hipGetErrorString(se));
+    }
     g_devices[id] = d;
     *out = d;
     return MDC_OK;
@@ -1326,11 +1330,26 @@ extern "C" int mdc_parse_device_noalloc(mdc_parser *p, const void *d_data, size_
     for (int c = 0; c < p->ncols; ++c) {
         if (!o->cols[c].d_off || !o->cols[c].d_bytes) return fail(MDC_ERR_ARG, "column %d: NULL output array", c);
         if (p->typed[c] != MDC_T_NONE && !o->cols[c].d_val) return fail(MDC_ERR_ARG, "column %d: typed, but no value array", c);
-        if (((uintptr_t)o->cols[c].d_off & 3) || ((uintptr_t)o->cols[c].d_val & 7))
+        // (the cells leave in 16-byte stores at the arena's own 16-byte phase)
+        if (((uintptr_t)o->cols[c].d_off & 3) || ((uintptr_t)o->cols[c].d_val & 7) || ((uintptr_t)o->cols[c].d_bytes & 15))
             return fail(MDC_ERR_ARG, "column %d: misaligned output array", c);
     }
     if (((uintptr_t)o->d_valid & 3) || ((uintptr_t)o->d_found & 3) || ((uintptr_t)o->d_rec_off & 7))
         return fail(MDC_ERR_ARG, "misaligned output array");
+    // Every call on a GPU works in that GPU's one scratch array: a second call that arrives while one is
+    // under way (another thread, another parser) is refused, not queued, since its kernels would overwrite
+    // the counters and places the first call's write pass is about to read.
+    Device *d = p->dev;
+    std::unique_lock<std::mutex> lk(d->noalloc_mu, std::try_to_lock);
+    if (!lk.owns_lock())
+        return fail(MDC_ERR_BUSY, "another mdc_parse_device_noalloc call is using the static scratch array of device %d", d->id);
+    if (!d->scratch_ready) {
+        // this device's copy of the array: its address is looked up once, with the device current
+        HIP_TRY(hipSetDevice(d->id));
+        const hipError_t e = noalloc_scratch_init(d->id);
+        if (e != hipSuccess) return fail(MDC_ERR_INTERNAL, "hipGetSymbolAddress of the static scratch array: %s", hipGetErrorString(e));
+        d->scratch_ready = true;
+    }
     return parse_impl(p, d_data, n, o, nullptr, rows, col_bytes);
 }
 
@@ -1396,11 +1415,25 @@ static hipError_t upload_host(Device *d, void *dbuf, const void *h_data, size_t 
         errs[t] = e != hipSuccess ? e : e2;
     };
     std::vector<std::thread> th;
-    for (size_t t = 1; t < T; ++t) th.emplace_back(work, t);
+    size_t started = 1;
+    try {  // (a thread that cannot be started must not throw through the C boundary)
+        for (size_t t = 1; t < T; ++t, ++started) th.emplace_back(work, t);
+    } catch (const std::system_error &) {
+    }
     work(0);
     for (auto &x : th) x.join();
-    for (size_t t = 0; t < T; ++t)
+    for (size_t t = 0; t < started; ++t)
         if (errs[t] != hipSuccess) return errs[t];
+    if (started < T) {
+        // the pieces of the threads that never ran: one plain copy each (piece k belongs to thread k % T)
+        for (size_t k = 0; k < npieces; ++k) {
+            if (k % T < started) continue;
+            const size_t off = k * PIECE, len = n - off < PIECE ? n - off : PIECE;
+            hipError_t e = hipMemcpyAsync((uint8_t *)dbuf + off, (const uint8_t *)h_data + off, len, hipMemcpyHostToDevice, d->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+            if (e != hipSuccess) return e;
+        }
+    }
     return hipSuccess;
 }
 
@@ -1431,7 +1464,13 @@ extern "C" int mdc_internal_parser_device(const mdc_parser *p) { return p->dev->
 // Test hook: the next parse on `p` adds `delta` to what its sizing pass counted for column `col` of
 // tile `tile`, as a sizing pass that disagreed with the write pass would have left it.  The write
 // pass must answer with MDC_ERR_INTERNAL and store nothing outside what was sized.
+// (Refused unless MDC_TEST_HOOKS is set in the environment when a hook is first called.)
+static bool test_hooks_on() {
+    static const bool on = getenv("MDC_TEST_HOOKS") != nullptr;
+    return on;
+}
 extern "C" int mdc_internal_skew_counts(mdc_parser *p, int tile, int col, int delta) {
+    if (!test_hooks_on()) return fail(MDC_ERR_ARG, "test hooks are off (MDC_TEST_HOOKS is not set)");
     if (!p) return fail(MDC_ERR_ARG, "NULL argument");
     p->skew_tile = tile;
     p->skew_col = col;
@@ -1757,6 +1796,7 @@ extern "C" void mdc_formatter_destroy(mdc_formatter *f) {
 
 // tuning hook for the measurement tools: LDS bytes a block of the formatting kernel may take
 extern "C" int mdc_internal_format_budget(mdc_formatter *f, int bytes) {
+    if (!test_hooks_on()) return fail(MDC_ERR_ARG, "test hooks are off (MDC_TEST_HOOKS is not set)");
     if (!f || bytes < 8 * 1024 || bytes > 60 * 1024) return fail(MDC_ERR_ARG, "budget out of range");
     f->lds_budget = (uint32_t)bytes;
     return MDC_OK;
@@ -2192,6 +2232,7 @@ extern "C" const char *mdc_strerror(int code) {
     case MDC_ERR_NUMERIC: return "numeric text beyond the exact-conversion range";
     case MDC_ERR_IO: return "I/O error";
     case MDC_ERR_INTERNAL: return "internal error";
+    case MDC_ERR_BUSY: return "the static scratch array is in use by another call";
     default: return "unknown error";
     }
 }

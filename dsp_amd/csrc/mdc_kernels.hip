@@ -2883,8 +2883,7 @@ __global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P, 
     if (!csv) {
         for (int64_t cb = gstart & ~(int64_t)15; cb < gend; cb += BLOCK * CHUNK) {
             const int64_t pos = cb + (int64_t)tid * CHUNK;
-            if (pos >= gend) continue;
-            uint32_t m = mask16_eq(gchunk(data, n, pos), 0x3C3C3C3Cu);
+            uint32_t m = pos < gend ? mask16_eq(gchunk(data, n, pos), 0x3C3C3C3Cu) : 0u;
             while (m) {
                 const int b = __builtin_ctz(m);
                 m &= m - 1;
@@ -2915,6 +2914,12 @@ __global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P, 
                     if (!slot) break;
                 }
             }
+            // Once every pattern has been seen the rest of the record cannot lower a first position:
+            // a record with all its tags near its head is not walked to its end.
+            __syncthreads();
+            bool missing = false;
+            for (uint32_t i = tid; i < 2 * ncols; i += BLOCK) missing |= first[i] == NONE;
+            if (!__syncthreads_or(missing)) break;
         }
     } else {
         // the first ncols separators, left to right without overlap (ccmdstr::splittocmd): all lanes

@@ -74,7 +74,8 @@ enum {
     MDC_ERR_TOO_LARGE = -6,     /* a column's cells exceed 4 GiB in one batch: split input    */
     MDC_ERR_NUMERIC = -7,       /* numeric text beyond the exact-conversion range            */
     MDC_ERR_IO = -8,
-    MDC_ERR_INTERNAL = -9
+    MDC_ERR_INTERNAL = -9,
+    MDC_ERR_BUSY = -10          /* mdc_parse_device_noalloc: another call is using the GPU's scratch array */
 };
 
 /* ---- options ------------------------------------------------------------------------ */
@@ -176,9 +177,12 @@ int mdc_parse_file(mdc_parser *p, const char *path, mdc_batch **out);
  *            MDC_ERR_TOO_LARGE before anything is written to the outputs
  *   results  *rows = records parsed; col_bytes (may be NULL) receives the ncols byte counts.
  *            The arrays hold what the batch of mdc_parse_device would hold, bit for bit
- *   sharing  every call on one GPU uses that GPU's one scratch array: calls that overlap on a GPU
- *            (two threads, two parsers) race; calls on different GPUs do not.  Nothing in the
- *            array needs clearing between calls (a call writes every word it later reads)
+ *   outputs' alignment: d_off 4, d_val 8, d_bytes 16 bytes (MDC_ERR_ARG otherwise); every array may be
+ *            sized exactly: nothing is stored behind rows + 1 offsets, rows values, col_bytes[c] bytes
+ *   sharing  every call on one GPU uses that GPU's one scratch array: a call that arrives while
+ *            another one is under way on the same GPU (two threads, two parsers) is refused with
+ *            MDC_ERR_BUSY; calls on different GPUs do not meet.  Nothing in the array needs
+ *            clearing between calls (a call writes every word it later reads)
  * It is the slower of the two entry points (no cell map is kept between the two passes). */
 typedef struct mdc_out_col {
     uint32_t *d_off;

@@ -852,6 +852,7 @@ def test_write_pass_refuses_a_tile_the_sizing_pass_measured_differently(port, de
     # that disagreed would have left it: the write pass must report an internal error (and store
     # nothing beyond what was sized) instead of handing out a batch, and the parser must stay usable.
     L = capi.lib()
+    os.environ["MDC_TEST_HOOKS"] = "1"  # (the hook is refused without it; read when a hook is first called)
     L.mdc_internal_skew_counts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     if full_write:  # no room in the cell map: every tile goes through tile_kernel<true>
         data = b"".join(b"%d,%d\n" % (i % 7, i % 3) for i in range(150000))

@@ -23,6 +23,7 @@ def main():
     p = capi.Parser.xml(cols, flags=capi.MDC_F_NO_RECOFF)
     f = capi.Formatter([c.colname for c in cols])
     if len(sys.argv) > 3:
+        os.environ["MDC_TEST_HOOKS"] = "1"
         capi.check(capi.lib().mdc_internal_format_budget(f.h, int(sys.argv[3])))
     b = p.parse_device(buf.ptr, buf.n)
     best = None
