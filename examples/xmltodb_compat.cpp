@@ -17,7 +17,13 @@
 #include <string>
 #include <vector>
 
+#ifdef MDC_WITH_REFERENCE_HEADER
+// the reference's own public/_public.h, guarded as tools/patch_public_for_compat.py guards it and compiled
+// with -DMDC_PARSE_COMPAT: it takes the declarations below from mdc_public_compat.h and keeps the rest
+#include "_public.h"
+#else
 #include "mdc_public_compat.h"
+#endif
 
 using namespace std;
 using namespace idc;
@@ -266,7 +272,26 @@ static int scalar_main() {
     return 0;
 }
 
+#ifdef MDC_WITH_REFERENCE_HEADER
+// What the toolkit keeps of its own beside the replaced functions: the sorted directory listing of
+// tools/xmltodb.cpp:147 (cdir, whose matchstr runs on the replaced ccmdstr and toupper) and a log file.
+static int dirlog_main(const char *dirname, const char *logname) {
+    clogfile logfile;
+    if (logfile.open(logname) == false) return 2;
+    cdir dir;
+    if (dir.opendir(dirname, "*.XML", 10000, false, true) == false) return 2;
+    while (dir.readdir()) {
+        logfile.write("%s %d\n", dir.m_filename.c_str(), dir.m_filesize);
+        printf("%s %d\n", dir.m_filename.c_str(), dir.m_filesize);
+    }
+    return 0;
+}
+#endif
+
 int main(int argc, char **argv) {
+#ifdef MDC_WITH_REFERENCE_HEADER
+    if (argc == 4 && string(argv[1]) == "dirlog") return dirlog_main(argv[2], argv[3]);
+#endif
     if (argc < 2) {
         fprintf(stderr, "usage: xmltodb_compat xml|bulk <file> <cols> [endbz] | records <cols> | csv ... | scalar\n");
         return 2;

@@ -14,7 +14,7 @@
  *   getxmlbuffer(xmlbuffer,fieldname,value[,ilen]) x 9     :140-148   host code, same results
  *   picknumber x 3                                         :65-67    host code, same results
  *   ccmdstr (splittocmd, size, cmdcount, [], 9 getvalue)   :81-122   host code, same results
- *   deletelchr/deleterchr/deletelrchr, toupper/tolower     :16-29    host code, same results
+ *   deletelchr/deleterchr/deletelrchr, toupper/tolower     :16-44    host code, same results
  *
  * The per-record functions take one record at a time, as their signatures demand, and are plain
  * host code here (written from the behaviour of public/_public.cpp:11-123, :167-211, :265-625,

@@ -126,7 +126,19 @@ typedef struct mdc_ingest_counts {
 
 /* Runs the loop over `rows` rows given as slabs in both bind orders (upd may be NULL when
  * uptbz != 1).  Returns MDC_OK whenever the decisions could be taken (look at counts->result);
- * the commit or rollback stays with the caller, who owns the connection. */
+ * the commit or rollback stays with the caller, who owns the connection.
+ *
+ * Order of the statements: the reference executes row by row, a rejected row's update before the
+ * next row's insert (tools/xmltodb.cpp:271-303); here ALL rows are inserted with one array execute and
+ * the rows rejected with ORA-00001 are then updated with a second one.  The table ends in the same
+ * state, and the counts are the same, when the primary key is the table's only unique constraint
+ * and no trigger or foreign key makes a row's outcome depend on the rows before it (the reference's
+ * own tables are of that kind: note.txt).  Where that does not hold (a second unique index: ORA-00001
+ * from it is answered by an update through the primary key, which may match no row; a trigger that
+ * reads earlier rows) keep the per-row order by calling this function with runs of rows, down to one
+ * row a call.  After a lost connection (result == 2) rows behind the fatal one have been sent to the
+ * database as part of the same array execute, and uptcount is 0: the caller rolls the file back, as
+ * the reference does (tools/xmltodb.cpp:297-301). */
 int mdc_ingest_rows(const mdc_bind_slab *ins, int nins, const mdc_bind_slab *upd, int nupd, int64_t rows, int uptbz,
                     mdc_array_exec exec, void *ctx, mdc_ingest_counts *counts);
 

@@ -1,4 +1,4 @@
-"""include/mdc_public_compat.h: the reference's declarations (public/_public.h:16-29, :65-67,
+"""include/mdc_public_compat.h: the reference's declarations (public/_public.h:16-44, :65-67,
 :81-122, :140-148, :401-430) under their own names and argument lists.  examples/xmltodb_compat.cpp
 makes the calls of tools/xmltodb.cpp:256-268 and :492-522 as they stand; its cells are held to the
 golden vectors (outputs of the reference's own code).  The per-record functions are host code and
