@@ -335,6 +335,24 @@ def e2e_section(a, parser, data, gz_files):
     out["gzip_sample"] = f"16 files of 32 MiB, gzip -6 ({sum(os.path.getsize(p) for p in paths) >> 20} MiB compressed), inflated by host threads (zlib)"
     for p in paths:
         os.remove(p)
+    # the reference's own record loop (cifile::open, readline("<endl/>") until the end, count) over
+    # include/mdc_public_compat.h: file -> pinned memory -> HBM -> record split on the GPU -> one
+    # std::string per record on the host; a child process, three timed rounds behind an untimed one
+    exe = os.path.join(ROOT, "examples", "xmltodb_compat")
+    if os.path.exists(exe) and paths:
+        f = os.path.join(os.path.dirname(paths[0]), "compat_readline.xml")
+        cut = int(np.flatnonzero(data[: 128 << 20] == 10)[-1]) + 1
+        data[:cut].tofile(f)
+        try:
+            r = subprocess.run([exe, "readloop", f, "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            rounds = [l.split() for l in r.stdout.splitlines() if l.startswith("round ")]
+            if r.returncode == 0 and rounds:
+                best = min(float(x[7]) for x in rounds)
+                out["compat_readline_GBps"] = round(cut / best / 1e9, 3)
+                out["compat_readline_records_per_s"] = round(int(rounds[0][3]) / best, 1)
+                out["compat_readline_sample"] = f"{cut} bytes, {rounds[0][3]} records, best of 3 rounds {best:.4f} s (file read, upload and the host's per-record strings included)"
+        finally:
+            os.remove(f)
     return out
 
 

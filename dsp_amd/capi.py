@@ -33,6 +33,7 @@ MDC_ERR_INTERNAL = -9
 MDC_ERR_BUSY = -10
 MDC_F_NO_RECOFF = 1
 MDC_F_ONE_PASS = 2
+MDC_F_RECORDS_ONLY = 4
 
 # every symbol include/mdc_parse.h declares
 EXPORTS = [
@@ -41,6 +42,7 @@ EXPORTS = [
     "mdc_parse_device", "mdc_parse_host", "mdc_parse_file", "mdc_parse_device_noalloc", "mdc_parser_last_timing",
     "mdc_parse_xml_buffer", "mdc_parse_xml_file", "mdc_parse_csv_buffer",
     "mdc_stream_open", "mdc_stream_next", "mdc_stream_bytes", "mdc_stream_close", "mdc_stream_release_pinned",
+    "mdc_host_buffer_get", "mdc_host_buffer_put",
     "mdc_batch_rows", "mdc_batch_ncols", "mdc_batch_words_per_row",
     "mdc_batch_device_column", "mdc_batch_device_values", "mdc_batch_device_masks", "mdc_batch_device_recoff",
     "mdc_batch_host_column", "mdc_batch_host_values", "mdc_batch_host_masks", "mdc_batch_host_recoff",

@@ -1090,6 +1090,12 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
     P.tmpl_sample = p->tmpl_sample;
     P.pub = d_pub;
     P.caps = p->d_caps;
+    if (p->flags & MDC_F_RECORDS_ONLY) {  // the record split alone: no template, no cell map (the full write kernel writes the rows)
+        P.records_only = 1;
+        P.use_tmpl = 0;
+        P.cellmap = nullptr;
+        P.map_cap = P.map_stride = 0;
+    }
     for (int t : p->typed)
         if (t == MDC_T_TIME || t == MDC_T_F32) P.special_cols = 1;
 #ifdef MDC_ABLATE

@@ -198,6 +198,7 @@ struct TileParams {
     uint32_t special_cols;       // the schema has time or binary32 columns (picks the write kernel's instance)
     uint32_t tmpl_sample;        // which record the template kernel samples: 0 = the second of the input, 1 = the third ...
     uint32_t debug;  // diagnostic builds only: phases to skip (ablation timing)
+    uint32_t records_only;  // the record split alone: no tag search, no cells (every cell comes out empty)
     // one-pass parse
     uint64_t *pub;          // [ncols+1][ntiles] published counts (PUB_*), zeroed before the launch
     const uint64_t *caps;   // [ncols+1] what the output arrays hold: bytes per column, then rows

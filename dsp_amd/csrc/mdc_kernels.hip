@@ -1920,7 +1920,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         __syncthreads();
         STAMP(2);  // clears
 
-        bool general = !csv && !SKIP(1);
+        bool general = !csv && !SKIP(1) && !P.records_only;
         if (tmode && general && !irregular) {
             // ---- C/D with the tag template.  Every record must have as many '<' as the sample ...
             if ((uint32_t)tid < RBn && (uint32_t)((int)e0t[tid + 1] - (int)e0t[tid]) != nT) ms[MS_IRR] = 1;
@@ -2191,6 +2191,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             }
         }
         if (fzb) {
+        } else if (P.records_only) {
+            // only the records' places are wanted (cifile::readline without a field schema): no tag search,
+            // no cells; every cell of the write pass is empty
+            if (WRITE && (uint32_t)tid < RBn)
+                for (uint32_t c = 0; c < ncols; ++c) O.off[c][row0 + rb0 + tid + 1] = 0;
         } else if (!WRITE && fastcsv) {
             // Delimited input whose separators were collected: one lane per (field, record).  Field c
             // lies between the record's separators c-1 and c; a field is text, so its length is all the

@@ -378,6 +378,16 @@ extern "C" int mdc_internal_pinned_get(size_t want, uint8_t **p, size_t *cap) {
 }
 extern "C" void mdc_internal_pinned_put(uint8_t *p, size_t cap) { pinned_put(p, cap); }
 
+extern "C" int mdc_host_buffer_get(size_t want, void **h_buf, size_t *cap) {
+    if (!h_buf || !cap) return mdc_internal_fail(MDC_ERR_ARG, "NULL argument");
+    PinnedBuf b;
+    if (!pinned_get(want ? want : 1, b)) return mdc_internal_fail(MDC_ERR_NOMEM, "hipHostMalloc failed");
+    *h_buf = b.p;
+    *cap = b.cap;
+    return MDC_OK;
+}
+extern "C" void mdc_host_buffer_put(void *h_buf, size_t cap) { pinned_put((uint8_t *)h_buf, cap); }
+
 extern "C" void mdc_stream_release_pinned(void) {
     std::vector<PinnedBuf> drop;
     {

@@ -8,6 +8,7 @@
 //   xmltodb_compat records <cols>              splitbuffer over records given on stdin (one per line, hex)
 //   xmltodb_compat csv <sephex> <bdelspace> <nfields> <ilen,..> <typed,..>   ccmdstr over lines given on stdin (hex)
 //   xmltodb_compat scalar                      single calls given on stdin, one per line (see scalar_main)
+//   xmltodb_compat readloop <file> [rounds]    the record loop alone (open, readline to the end), timed per round
 //
 // <cols> = namehex:datatype:collen,...   Output: one line per record, "row cellhex cellhex ..." ("-" = empty cell).
 #include <cstdio>
@@ -272,6 +273,28 @@ static int scalar_main() {
     return 0;
 }
 
+// The reference's record loop alone (tools/xmltodb.cpp:256-266: open, readline until the end, count), timed:
+// a first untimed round (the GPU runtime starts, buffers get pinned), then `rounds` timed ones.
+#include <chrono>
+static int readloop_main(const string &file, int rounds) {
+    for (int k = 0; k <= rounds; ++k) {
+        const auto t0 = std::chrono::steady_clock::now();
+        cifile ifile;
+        if (ifile.open(file) == false) return 5;
+        long totalcount = 0;
+        size_t bytes = 0;
+        string strbuffer;
+        while (ifile.readline(strbuffer, "<endl/>")) {
+            totalcount++;
+            bytes += strbuffer.size() + 1;
+        }
+        if (ifile.errcode() != MDC_OK) return 2;
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (k) printf("round %d records %ld bytes %zu seconds %.6f\n", k, totalcount, bytes, s);
+    }
+    return 0;
+}
+
 #ifdef MDC_WITH_REFERENCE_HEADER
 // What the toolkit keeps of its own beside the replaced functions: the sorted directory listing of
 // tools/xmltodb.cpp:147 (cdir, whose matchstr runs on the replaced ccmdstr and toupper) and a log file.
@@ -297,6 +320,7 @@ int main(int argc, char **argv) {
         return 2;
     }
     const string mode = argv[1];
+    if (mode == "readloop" && argc >= 3) return readloop_main(argv[2], argc >= 4 ? atoi(argv[3]) : 3);
     if (mode == "scalar") return scalar_main();
     if (mode == "csv") return csv_main(argc, argv);
     if (mode == "records") return argc >= 3 && parse_cols(argv[2]) ? records_main() : 2;

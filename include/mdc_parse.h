@@ -94,6 +94,9 @@ typedef struct mdc_opts {
 
 enum {
     MDC_F_NO_RECOFF = 1u, /* do not materialise the record-offset array                     */
+    MDC_F_RECORDS_ONLY = 4u, /* the record split alone (cifile::readline, public/_public.cpp:866-892, over a whole */
+                          /* file): rows and record offsets are right, every cell is empty and no tag is looked  */
+                          /* for; about twice as fast as a parse with a schema                                      */
     MDC_F_ONE_PASS = 2u   /* tagged input, from the parser's second parse on: size and write in ONE kernel.  The */
                           /* output arrays are sized from the previous parse with a margin and every tile      */
                           /* learns its place from the tiles in front of it inside the launch; an input that    */
@@ -232,6 +235,12 @@ void mdc_stream_close(mdc_stream *s);
  * pinning memory costs about as much as reading a file into it, and the ingest opens a stream per
  * directory scan, tools/xmltodb.cpp:147-218).  This gives them back to the system. */
 void mdc_stream_release_pinned(void);
+/* A host buffer of at least `want` bytes in pinned memory: one of the buffers above when one fits, else
+ * newly pinned; *cap receives its size.  Input read into such a buffer goes to the GPU in one copy
+ * (mdc_parse_host).  mdc_host_buffer_put hands it back for the next user.  Host-side helpers without a
+ * counterpart in the reference (its cifile reads through an ifstream, public/_public.cpp:828-838). */
+int mdc_host_buffer_get(size_t want, void **h_buf, size_t *cap);
+void mdc_host_buffer_put(void *h_buf, size_t cap);
 
 /* ---- batches ------------------------------------------------------------------------ */
 

@@ -320,23 +320,47 @@ class cifile {
 
     bool isopen() const { return m_open; }
 
-    /* Reads the whole file (the mode is accepted for the signature's sake; bytes are taken as
-     * they are, which is what the reference's text mode does on Linux).  false when the file cannot
-     * be opened or read, or when there is no usable GPU to split it with (errcode() tells which). */
+    /* Reads the whole file into pinned host memory, from where it goes to the GPU in one copy (the mode
+     * is accepted for the signature's sake; bytes are taken as they are, which is what the reference's
+     * text mode does on Linux).  false when the file cannot be opened or read, or when there is no
+     * usable GPU to split it with (errcode() tells which). */
     bool open(const std::string &filename, const std::ios::openmode mode = std::ios::in) {
         (void)mode;
         close();
         m_filename = filename;
-        std::ifstream fin(filename, std::ios::in | std::ios::binary);
-        if (!fin.is_open()) return fail(MDC_FILE_OPEN_FAILED, "cannot open " + filename);
-        fin.seekg(0, std::ios::end);
-        const std::streamoff n = fin.tellg();
-        fin.seekg(0, std::ios::beg);
-        m_data.resize((size_t)(n > 0 ? n : 0));
-        if (n > 0 && !fin.read(&m_data[0], n)) return fail(MDC_ERR_IO, "cannot read " + filename);
+        std::FILE *f = std::fopen(filename.c_str(), "rb");
+        if (!f) return fail(MDC_FILE_OPEN_FAILED, "cannot open " + filename);
         const int ndev = mdc_device_count();
-        if (ndev < 1)
+        if (ndev < 1) {
+            std::fclose(f);
             return fail(MDC_ERR_NO_DEVICE, ndev < 0 ? std::string("no usable GPU: ") + mdc_last_error() : std::string("no usable GPU"));
+        }
+        /* (a file that grows while it is read: the buffer grows with it) */
+        size_t cap = 0;
+        for (;;) {
+            if (m_size == cap) {
+                void *q = nullptr;
+                size_t qcap = 0;
+                std::fseek(f, 0, SEEK_END);
+                const long end = std::ftell(f);
+                std::fseek(f, (long)m_size, SEEK_SET);
+                const size_t want = (end > 0 && (size_t)end > m_size ? (size_t)end : m_size) + 4096;
+                if (mdc_host_buffer_get(want, &q, &qcap) != MDC_OK) {
+                    std::fclose(f);
+                    return fail(MDC_ERR_NOMEM, std::string("no pinned memory for ") + filename);
+                }
+                if (m_size) std::memcpy(q, m_buf, m_size);
+                if (m_buf) mdc_host_buffer_put(m_buf, m_cap);
+                m_buf = (char *)q;
+                m_cap = cap = qcap;
+            }
+            const size_t got = std::fread(m_buf + m_size, 1, cap - m_size, f);
+            m_size += got;
+            if (got == 0) break;
+        }
+        const bool bad = std::ferror(f) != 0;
+        std::fclose(f);
+        if (bad) return fail(MDC_ERR_IO, "cannot read " + filename);
         m_open = true;
         m_pos = 0;
         m_rc = MDC_OK;
@@ -366,14 +390,15 @@ class cifile {
         while (lo < (size_t)m_nrec && m_recoff[lo + 1] - 1 - m_pos < el) ++lo;
         if (lo >= (size_t)m_nrec) {
             /* no further record: the reference has by now appended every remaining complete line */
-            const size_t nl = m_data.rfind('\n');
-            if (nl != std::string::npos && nl >= m_pos) buf.assign(m_data, m_pos, nl + 1 - m_pos);
-            m_pos = m_data.size();
+            size_t nl = m_size;
+            while (nl > m_pos && m_buf[nl - 1] != '\n') --nl;  /* one behind the last '\n' at or behind the position */
+            if (nl > m_pos) buf.assign(m_buf + m_pos, nl - m_pos);
+            m_pos = m_size;
             m_eof = true;
             return false;
         }
         const size_t end = (size_t)m_recoff[lo + 1];  /* one behind the terminating '\n' */
-        buf.assign(m_data, m_pos, end - 1 - m_pos);
+        buf.assign(m_buf + m_pos, end - 1 - m_pos);
         m_pos = end;
         return true;
     }
@@ -381,8 +406,8 @@ class cifile {
     /* bytes from the current position, as many as there are (at most bufsize); their count */
     int read(void *buf, const int bufsize) {
         if (!m_open || bufsize <= 0 || m_eof) return 0;
-        const size_t left = m_data.size() - m_pos, n = left < (size_t)bufsize ? left : (size_t)bufsize;
-        std::memcpy(buf, m_data.data() + m_pos, n);
+        const size_t left = m_size - m_pos, n = left < (size_t)bufsize ? left : (size_t)bufsize;
+        std::memcpy(buf, m_buf + m_pos, n);
         m_pos += n;
         if (n < (size_t)bufsize) m_eof = true;
         return (int)n;
@@ -405,7 +430,9 @@ class cifile {
         m_nrec = 0;
         m_pos = 0;
         m_recoff = nullptr;
-        std::string().swap(m_data);
+        if (m_buf) mdc_host_buffer_put(m_buf, m_cap);
+        m_buf = nullptr;
+        m_size = m_cap = 0;
     }
 
     /* ---- beyond the reference's interface ------------------------------------------------- */
@@ -426,7 +453,7 @@ class cifile {
         o.carry = 1;
         o.typed = typed;
         mdc_batch *b = nullptr;
-        const int rc = mdc_parse_xml_buffer(m_data.data(), m_data.size(), cols, ncols, &o, &b);
+        const int rc = mdc_parse_xml_buffer(m_buf, m_size, cols, ncols, &o, &b);
         if (rc != MDC_OK) {
             fail(rc, mdc_last_error());
             return nullptr;
@@ -449,7 +476,8 @@ class cifile {
         m_split = false;
         if (endbz.size() > 32 || endbz.find('\n') != std::string::npos || endbz.find('\0') != std::string::npos)
             return fail(MDC_ERR_ARG, "readline: an end mark with a newline, a NUL or more than 32 bytes is not supported");
-        /* a schema of one column whose tag no file holds: only the record offsets are wanted */
+        /* only the record offsets are wanted: the record split alone (the one column a schema must have
+         * gets no cells) */
         mdc_col col;
         std::memset(&col, 0, sizeof col);
         std::strcpy(col.colname, "\x01");
@@ -459,8 +487,9 @@ class cifile {
         std::memset(&o, 0, sizeof o);
         o.endbz = endbz.c_str();
         o.typed = &untyped;
+        o.flags = MDC_F_RECORDS_ONLY;
         int rc = mdc_parser_create_xml(&col, 1, &o, &m_parser);
-        if (rc == MDC_OK) rc = mdc_parse_host(m_parser, m_data.data(), m_data.size(), &m_batch);
+        if (rc == MDC_OK) rc = mdc_parse_host(m_parser, m_buf, m_size, &m_batch);
         if (rc == MDC_OK) rc = mdc_batch_host_recoff(m_batch, &m_recoff);
         if (rc != MDC_OK) return fail(rc, mdc_last_error());
         m_nrec = mdc_batch_rows(m_batch);
@@ -469,7 +498,9 @@ class cifile {
         return true;
     }
 
-    std::string m_filename, m_data, m_endbz, m_err;
+    std::string m_filename, m_endbz, m_err;
+    char *m_buf = nullptr;  /* the file's bytes, in pinned host memory of the library's pool */
+    size_t m_size = 0, m_cap = 0;
     bool m_open = false, m_split = false, m_eof = false;
     size_t m_pos = 0;
     mdc_parser *m_parser = nullptr;
