@@ -48,6 +48,43 @@ def test_eight_shares_of_an_archive_on_one_gpu(tmp_path, port):
     p.close()
 
 
+def test_one_ranks_share_of_the_64_gib_archive_at_full_file_size(port):
+    """Rank 0 of 8's share of the 64 GiB archive (512 files of 128 MiB: files 0, 8, 16, ...) at the files'
+    real size, as many of its 64 files as /dev/shm holds (16 at least): every file's rows against the
+    generator's, the batches in list order, one whole 128 MiB file cell for cell against the CPU checker."""
+    import shutil
+    import tempfile
+    nfiles_total, world, file_bytes = 512, 8, 128 << 20
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    free = shutil.disk_usage(base).free
+    share = archive.rank_share(nfiles_total, 0, world)
+    assert share == list(range(0, nfiles_total, world)) and len(share) == 64
+    take = 64 if free > (12 << 30) else 16
+    if free < (3 << 30):
+        pytest.skip("no room for 16 files of 128 MiB")
+    d = tempfile.mkdtemp(prefix="mdc_share_", dir=base)
+    try:
+        mine = share[:take]
+        paths, rows_exp, nbytes = archive.make_files(d, mine, file_bytes, workers=8)
+        assert paths == sorted(paths) and all(b > (127 << 20) for b in nbytes)
+        p = capi.Parser.xml(schema.ZHOBTMIND)
+        keep = []
+        res = archive.run_share(p, paths, threads=8, keep=keep)
+        assert not res.errors
+        assert res.rows_per_file == rows_exp and res.rows == sum(rows_exp)
+        assert [k for k, _ in keep] == list(range(take))
+        for j, b in keep:  # the key column's first cell names the file
+            assert int(b.cell(0, 10)) == 1_000_000 + mine[j] * archive.ROWS_PER_FILE_STRIDE
+        k = take // 2
+        data = np.fromfile(paths[k], dtype=np.uint8)
+        assert_batches_equal(keep[k][1].to_host(), port.parse_xml(data, schema.ZHOBTMIND), f"file {mine[k]} of rank 0")
+        for _, b in keep:
+            b.free()
+        p.close()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def test_bench_starts_its_own_ranks(tmp_path):
     # the documented command, in small: no launcher around it, two ranks (sharing this box's GPU)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",

@@ -716,7 +716,7 @@ def test_delimited_long_batch_with_trim(port, bdel):
     assert_batches_equal(got, exp, "delimited, many tiles")
 
 
-def _whole_equals_parts_and_checker_windows(port, data, n, p, parse_window, endbz, nwindows=6, window=4 << 20):
+def _whole_equals_parts_and_checker_windows(port, data, n, p, parse_window, endbz, nwindows=16, window=4 << 20):
     """The parse of the whole batch equals the concatenation of the parses of four parts cut at record
     terminators (rows match the generator's count), and windows of the batch spread over its whole length,
     cut at record boundaries and parsed by the CPU checker, equal the rows of the whole parse they cover."""

@@ -45,11 +45,24 @@ def _avg(passdir, counter, kernel_sub):
             per[row["Dispatch_Id"]] += float(row["Counter_Value"])
     return sum(per.values()) / len(per) if per else None
 
-kernel_sub = "emit_kernel" if len(sys.argv) < 3 else sys.argv[2]
-f, w = _avg("pmc3", "FETCH_SIZE", kernel_sub), _avg("pmc4", "WRITE_SIZE", kernel_sub)
-if f is not None and w is not None:
-    t = {"kernel": kernel_sub, "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
-         "traffic_bytes": 2 * f * 1024 + w * 1024,
+# Both kernels of a parse: {"sizing": the tile kernel's sizing instance, "write": the emit kernel}.
+# usage: pmc_summary.py <dir> [sizing kernel substring] [write kernel substring]
+subs = {"sizing": sys.argv[2] if len(sys.argv) > 2 else "tile_kernel<0>", "write": sys.argv[3] if len(sys.argv) > 3 else "emit_kernel"}
+kernels = {}
+for role, sub in subs.items():
+    f, w = _avg("pmc3", "FETCH_SIZE", sub), _avg("pmc4", "WRITE_SIZE", sub)
+    if f is not None and w is not None:
+        kernels[role] = {"kernel": sub, "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024, "traffic_bytes": 2 * f * 1024 + w * 1024}
+if kernels:
+    t = {"kernels": kernels,
          "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; KB units; FETCH_SIZE doubled (gfx950)"}
+    # the batch the profiled bench run parsed (its JSON line in trace.log)
+    try:
+        for line in open(os.path.join(out, "trace.log")):
+            if line.startswith("{") and "bytes_per_gpu" in line:
+                t["workload_bytes"] = json.loads(line)["config"]["bytes_per_gpu"]
+    except (OSError, ValueError, KeyError):
+        pass
+    t["source"] = out
     json.dump(t, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     print("== traffic per launch:", json.dumps(t))
