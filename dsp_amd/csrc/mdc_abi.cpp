@@ -405,13 +405,15 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
     const uint32_t ncols = (uint32_t)p->ncols;
     const uint32_t npat = p->mode == MODE_XML ? 2 * ncols : 0;
     size_t el = strlen(endbz);
-    if (el > MAX_ENDBZ) return fail(MDC_ERR_ARG, "endbz longer than %d bytes", MAX_ENDBZ);
+    if (el > MAX_LONG_TEXT) return fail(MDC_ERR_ARG, "endbz longer than %d bytes", MAX_LONG_TEXT);
+    // (An end mark that holds a newline may overlap the terminator in front of it, and whether it counts then
+    // depends on where the record began: cifile::readline matches the mark within the record it has gathered
+    // so far.  That makes the split a left-to-right decision over the whole file, which this parser does not take.)
     if (memchr(endbz, '\n', el)) return fail(MDC_ERR_ARG, "endbz must not contain a newline");
     size_t sl = 0;
     if (p->mode == MODE_CSV) {
         sl = strlen(sep);
-        if (sl == 0 || sl > MAX_SEP) return fail(MDC_ERR_ARG, "separator must be 1..%d bytes", MAX_SEP);
-        if (memchr(sep, '\n', sl)) return fail(MDC_ERR_ARG, "separator must not contain a newline");
+        if (sl == 0 || sl > MAX_LONG_TEXT) return fail(MDC_ERR_ARG, "separator must be 1..%d bytes", MAX_LONG_TEXT);
     }
     std::vector<DevCol> dc(ncols);
     uint32_t any_typed = 0;
@@ -533,7 +535,9 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
     }
 
     const size_t cols_bytes = (ncols * sizeof(DevCol) + 15) & ~(size_t)15;
-    const size_t p10_off = sizeof(SchemaHdr) + cols_bytes + ht.size() * sizeof(HtEntry);
+    // (an end mark or a separator too long for the header lies in front of the table of powers of ten)
+    const size_t text_off = sizeof(SchemaHdr) + cols_bytes + ht.size() * sizeof(HtEntry);
+    const size_t p10_off = text_off + long_text_room((uint32_t)el, MAX_ENDBZ) + long_text_room((uint32_t)sl, MAX_SEP);
     p->blob.assign(p10_off + P10_TABLE_DOUBLES * sizeof(double), 0);
     p->blob.resize((p->blob.size() + 15) & ~(size_t)15);
     SchemaHdr *H = (SchemaHdr *)p->blob.data();
@@ -549,10 +553,12 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
     H->any_typed = any_typed;
     H->tz_offset = tz_offset;
     H->endbz_len = (uint32_t)el;
-    memcpy(H->endbz, endbz, el);
+    memcpy(H->endbz, endbz, el < MAX_ENDBZ ? el : MAX_ENDBZ);
     if (el <= 8) memcpy(H->endbz_tail + 8 - el, endbz, el);
     H->sep_len = (uint32_t)sl;
-    if (sl) memcpy(H->sep, sep, sl);
+    if (sl) memcpy(H->sep, sep, sl < MAX_SEP ? sl : MAX_SEP);
+    if (el > MAX_ENDBZ) memcpy(p->blob.data() + text_off, endbz, el);
+    if (sl > MAX_SEP) memcpy(p->blob.data() + text_off + long_text_room((uint32_t)el, MAX_ENDBZ), sep, sl);
     H->sep_fast = sl >= 1 && sl <= 4;
     for (size_t k = 0; k < sl && k < 4; ++k)
         if ((uint8_t)sep[k] >= 0x80 || sep[k] == '\n') H->sep_fast = 0;

@@ -19,8 +19,9 @@ constexpr int DATA_SLACK = 64;                           // readable bytes past 
 constexpr int LB_FIRST = 512;                            // first look-behind window
 constexpr int LB_STEP = BLOCK * CHUNK;                   // later windows
 constexpr int MAX_COLS = 128;
-constexpr int MAX_ENDBZ = 32;
+constexpr int MAX_ENDBZ = 32;       // end marks and separators up to these lengths lie in the schema header ...
 constexpr int MAX_SEP = 16;
+constexpr int MAX_LONG_TEXT = 255;  // ... longer ones (up to this) in front of the table of powers of ten, see long_text
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 // The table of powers of ten at SchemaHdr::p10_off (16-byte aligned): double[23] = 10^0 .. 10^22, one
 // double of padding, then P10_PAIRS pairs {10^k, 1 / 10^k} (the quotient of an integer below 10^8 by
@@ -125,9 +126,22 @@ struct SchemaHdr {
     int32_t tz_offset;      // MDC_T_TIME columns: seconds east of UTC of the zone mktime would run in
     uint8_t sep_fast;       // delimited mode: the separator (1 to 4 bytes below 0x80, no '\n') is found with byte masks
     uint8_t pad3[3];
-    // followed by DevCol[ncols], HtEntry[ht_mask+1+chained] (16-byte aligned), double[23]
+    // followed by DevCol[ncols], HtEntry[ht_mask+1+chained] (16-byte aligned), an end mark longer than
+    // MAX_ENDBZ and a separator longer than MAX_SEP (each padded to 16 bytes; the header's arrays then hold
+    // their first bytes), double[23]
 };
 static_assert(sizeof(SchemaHdr) % 16 == 0, "SchemaHdr must keep 16-byte alignment");
+
+// The end mark and the separator of a schema blob that begins at H (in LDS or in global memory).
+MDC_HD inline uint32_t long_text_room(uint32_t len, uint32_t in_header) { return len > in_header ? (len + 15) & ~15u : 0; }
+MDC_HD inline const uint8_t *sep_text(const SchemaHdr *H) {
+    return H->sep_len <= (uint32_t)MAX_SEP ? H->sep : (const uint8_t *)H + H->p10_off - long_text_room(H->sep_len, MAX_SEP);
+}
+MDC_HD inline const uint8_t *endbz_text(const SchemaHdr *H) {
+    return H->endbz_len <= (uint32_t)MAX_ENDBZ
+               ? H->endbz
+               : (const uint8_t *)H + H->p10_off - long_text_room(H->sep_len, MAX_SEP) - long_text_room(H->endbz_len, MAX_ENDBZ);
+}
 
 // byte offsets of the LDS regions (computed on the host from the schema)
 struct LdsLayout {

@@ -285,8 +285,9 @@ __device__ __forceinline__ bool is_term(const uint8_t *sdata, const SchemaHdr *H
         const uint64_t m = ~0ull << (8 * (8 - el));
         return ((w ^ want) & m) == 0;
     }
+    const uint8_t *mark = endbz_text(H);
     for (int k = 0; k < el; ++k)
-        if (sdata[p - el + k] != H->endbz[k]) return false;
+        if (sdata[p - el + k] != mark[k]) return false;
     return true;
 }
 
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(64) void template_kernel(const TileParams P) {
             nlm &= nlm - 1;
             const int p = lane * 64 + b;
             bool t = p - el >= 0;
-            for (int k = 0; t && k < el; ++k) t = win[p - el + k] == H->endbz[k];
+            for (int k = 0; t && k < el; ++k) t = win[p - el + k] == endbz_text(H)[k];
             if (t) tm |= 1ull << b;
         }
     }
@@ -1629,7 +1630,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                     for (int k = 0; t && k < el; ++k) {
                         const int li = p - el + k;
                         const uint32_t bb = li >= lo_li ? sdata[li] : P.data[base_pos + li];
-                        t = bb == H->endbz[k];
+                        t = bb == endbz_text(H)[k];
                     }
                 }
                 if (t) atomicMax((int *)&ms[MS_LAST], p);
@@ -2007,6 +2008,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                 uint32_t pos = rs;
                 bool done = false;
                 const uint32_t s0b = H->sep[0];
+                const uint8_t *sepp = sep_text(H);
                 for (uint32_t c = 0; c < ncols; ++c) {
                     uint32_t fs = pos, fl = 0;
                     if (!done) {
@@ -2016,7 +2018,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                             if (sdata[p] == s0b) {
                                 bool eq = true;
                                 for (uint32_t k = 1; k < seplen; ++k)
-                                    if (sdata[p + k] != H->sep[k]) {
+                                    if (sdata[p + k] != sepp[k]) {
                                         eq = false;
                                         break;
                                     }
@@ -2814,8 +2816,9 @@ __device__ __forceinline__ uint4 gchunk(const uint8_t *data, int64_t n, int64_t 
 __device__ __forceinline__ bool gterm(const uint8_t *data, const SchemaHdr *H, int64_t p) {  // is the '\n' at p a terminator?
     const int el = (int)H->endbz_len;
     if (p - el < 0) return el == 0;
+    const uint8_t *mark = endbz_text(H);
     for (int k = 0; k < el; ++k)
-        if (data[p - el + k] != H->endbz[k]) return false;
+        if (data[p - el + k] != mark[k]) return false;
     return true;
 }
 // does byte k of a cell pass the filter of its level?
@@ -2941,7 +2944,7 @@ __global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P, 
                     m &= m - 1;
                     const int64_t q = pos + b;
                     bool ok = q >= gstart && q + seplen <= gend;
-                    for (uint32_t k = 1; ok && k < seplen; ++k) ok = data[q + k] == H->sep[k];
+                    for (uint32_t k = 1; ok && k < seplen; ++k) ok = data[q + k] == sep_text(H)[k];
                     if (ok) keep |= 1u << b;
                 }
                 m = keep;

@@ -140,14 +140,18 @@ const char *mdc_last_error(void);
 /* Replaces, per record: cifile::readline(buf,endbz) (public/_public.cpp:866-892) +
  * splitbuffer (tools/xmltodb.cpp:492-522), i.e. getxmlbuffer(xml,colname,temp,collen)
  * (public/_public.cpp:461-481) + picknumber(temp,temp,..) (public/_public.cpp:178-204) +
- * vcolvalue[i]=temp.c_str() for every column of the schema.  Column names must not contain
- * '>' or '\n' and the schema may hold at most 128 columns (MDC_ERR_ARG otherwise). */
+ * vcolvalue[i]=temp.c_str() for every column of the schema.  Limits (MDC_ERR_ARG beyond them; the
+ * reference has none): column names without '>' and '\n', at most 128 columns, an end mark
+ * (opts->endbz) of at most 255 bytes without '\n'.  (An end mark that holds a newline may overlap the
+ * terminator in front of it, and cifile::readline only matches it within the record gathered so far:
+ * the split would then be a left-to-right decision over the whole file.) */
 int mdc_parser_create_xml(const mdc_col *cols, int ncols, const mdc_opts *opts, mdc_parser **out);
 
 /* Replaces, per line: cifile::readline(buf) + ccmdstr::splittocmd(buf,sep,bdelspace)
  * (public/_public.cpp:274-302) + getvalue(f,string&,ilen[f]) (:304-317) and the typed
- * getvalue overloads (:339-446) for fields 0..nfields-1.  sep must be 1..16 bytes without
- * '\n'.  opts->typed/ilen may be NULL. */
+ * getvalue overloads (:339-446) for fields 0..nfields-1.  sep has 1..255 bytes (up to four bytes
+ * below 0x80 without '\n' are found with byte masks, other separators by a walk over each record).
+ * opts->typed/ilen may be NULL. */
 int mdc_parser_create_csv(const char *sep, int bdelspace, int nfields, const int *ilen,
                           const mdc_opts *opts, mdc_parser **out);
 

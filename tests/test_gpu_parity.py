@@ -901,3 +901,58 @@ def test_bind_slabs_of_every_column_with_carried_values(port):
             assert row[:len(cell)] == cell and row[len(cell):] == b"\0" * (stride - len(cell)), (r, c)
     b.free()
     p.close()
+
+
+@pytest.mark.parametrize("seplen", [5, 16, 17, 40, 255])
+def test_long_separators(port, seplen):
+    """ccmdstr::splittocmd (public/_public.cpp:274-302) puts no bound on the separator: beyond four bytes it is
+    found by the walk over each record, beyond sixteen its text lies behind the schema's tables."""
+    rng = np.random.default_rng(seplen)
+    sep = "".join(chr(int(c)) for c in rng.integers(33, 127, seplen))
+    lines = []
+    for i in range(3000):
+        f = [str(int(rng.integers(0, 10 ** int(rng.integers(1, 8))))) for _ in range(int(rng.integers(1, 6)))]
+        if i % 11 == 0:
+            f.append(sep[: seplen // 2])  # (half a separator is field text)
+        lines.append(sep.join(f))
+    data = ("\n".join(lines) + "\n").encode("latin-1")
+    typed = [schema.T_I64, schema.T_F64, schema.T_NONE, schema.T_U32, schema.T_NONE]
+    got = gpu_csv(data, sep, 5, typed=typed, bdelspace=seplen % 2 == 1, ilen=[0, 0, 4, 0, 0])
+    exp = port.parse_csv(data, sep, 5, ilen=[0, 0, 4, 0, 0], typed=typed, bdelspace=seplen % 2 == 1)
+    assert_batches_equal(got, exp, f"separator of {seplen} bytes")
+
+
+def test_separator_with_a_newline_never_matches_in_a_line(port):
+    # a line holds no newline, so a separator with one is never found: every line is one field (the reference
+    # takes such a separator; it used to be refused here)
+    data = b"".join(b"a%d|\n|b%d\n" % (i, i) for i in range(3000))
+    got = gpu_csv(data, "|\n|", 3, typed=[schema.T_NONE, schema.T_NONE, schema.T_I64])
+    exp = port.parse_csv(data, "|\n|", 3, typed=[schema.T_NONE, schema.T_NONE, schema.T_I64])
+    assert got.rows == 6000
+    assert_batches_equal(got, exp, "separator with a newline")
+
+
+@pytest.mark.parametrize("marklen", [9, 32, 33, 100, 255])
+def test_long_end_marks(port, marklen):
+    """cifile::readline (public/_public.cpp:866-892) takes an end mark of any length: beyond 32 bytes its text
+    lies behind the schema's tables.  Marks cut short, and marks with text behind them, end no record."""
+    rng = np.random.default_rng(marklen)
+    mark = "".join(chr(int(c)) for c in rng.integers(33, 127, marklen)).replace("<", "(")
+    recs = []
+    for i in range(4000):
+        body = "<a>%d</a><b>%d.5</b>" % (i, i % 977)
+        if i % 13 == 0:
+            body += mark[:-1] + "\n"          # (all but the mark's last byte, then a newline: no terminator)
+        if i % 17 == 0:
+            body += mark + "x\n"              # (the mark with text behind it: no terminator)
+        recs.append(body + mark + "\n")
+    data = ("".join(recs) + "<a>tail</a>" + mark).encode("latin-1")  # (a last record without its newline is dropped)
+    got = gpu_xml(data, cases.SMALL, endbz=mark)
+    exp = port.parse_xml(data, cases.SMALL, endbz=mark)
+    assert got.rows == 4000
+    assert_batches_equal(got, exp, f"end mark of {marklen} bytes")
+    # ... and through a long record (the long-record kernel reads the mark as well)
+    big = ("<a>1</a>" + "j" * 40000 + mark + "\n").encode("latin-1")
+    got = gpu_xml(data[: len(data) // 2] + big + data[len(data) // 2:], cases.SMALL, endbz=mark)
+    exp = port.parse_xml(data[: len(data) // 2] + big + data[len(data) // 2:], cases.SMALL, endbz=mark)
+    assert_batches_equal(got, exp, f"end mark of {marklen} bytes, long record")
