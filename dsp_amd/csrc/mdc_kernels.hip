@@ -421,20 +421,22 @@ __device__ __forceinline__ uint32_t tag_lookup(const uint8_t *sdata, const Schem
 // the sample's byte for byte; then the event matches what the sample's did, and its position goes
 // to first_pos[pattern][record] with a plain store (in a record that repeats the sample no
 // pattern occurs twice).  false = the record does not follow the template.
+// (tl: the entries as the tile kernel keeps them in LDS, the pattern index replaced by the pattern's row of
+// first_pos, index x records per batch, so that no multiplication stands in the walk)
 __device__ __forceinline__ bool tmpl_event(const uint8_t *sdata, const uint4 *tl, uint32_t nT, uint32_t q, uint32_t k,
-                                           uint32_t *evt, uint32_t rl, uint32_t RB) {
+                                           uint32_t *evt, uint32_t rl) {
     if (k >= nT) return false;
     const uint4 t = tl[k];
     uint32_t w0, w1, w2;
     lds_bytes12(sdata + q + 1, w0, w1, w2);
     const uint64_t w = (uint64_t)w0 | ((uint64_t)w1 << 32);
     // the bytes that do not belong to the text are shifted out (the shift counts come with the entry)
-    const uint32_t sh1 = t.w & 0xFFu, sh2 = (t.w >> 8) & 0xFFu, idx = t.w >> 16;
+    const uint32_t sh1 = t.w & 0xFFu, sh2 = (t.w >> 8) & 0xFFu, row = t.w >> 16;
     const uint64_t key = (uint64_t)t.x | ((uint64_t)t.y << 32);
     const uint64_t d1 = (w ^ key) << sh1;
     const uint32_t d2 = (uint32_t)((uint64_t)(w2 ^ t.z) << sh2);
     const bool ok = (d1 == 0) & (d2 == 0);
-    if (ok && idx != TMPL_NOPAT) ((uint16_t *)evt)[idx * RB + rl] = (uint16_t)q;
+    if (ok && row != TMPL_NOPAT) ((uint16_t *)evt)[row + rl] = (uint16_t)q;
     return ok;
 }
 
@@ -1586,7 +1588,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         for (int k = 0; k < 4; ++k) ((uint4 *)sdata)[ts_li / CHUNK + k * BLOCK + tid] = tv[k];
         if (lbmine) ((uint4 *)sdata)[jlb] = lbv;
         if ((uint32_t)tid < sch16) s[tid] = sv;
-        if (P.use_tmpl && tid >= 1 && (uint32_t)tid <= tmpl_cap) tmpl_l[tid - 1] = tq;
+        if (P.use_tmpl && tid >= 1 && (uint32_t)tid <= tmpl_cap) {
+            // (pattern index -> the pattern's row of first_pos: at most 255 x 128 entries, below TMPL_NOPAT)
+            uint4 e = tq;
+            const uint32_t idx = e.w >> 16;
+            e.w = (e.w & 0xFFFFu) | ((idx == TMPL_NOPAT ? TMPL_NOPAT : idx * L.RB) << 16);
+            tmpl_l[tid - 1] = e;
+        }
         if (P.use_tmpl && tmpl_room && (uint32_t)tid > TMPL_MAX && (uint32_t)tid <= TMPL_MAX + plan16)
             ((uint4 *)plan_l)[tid - 1 - TMPL_MAX] = tq;
         for (uint32_t i = tid + BLOCK; i < sch16; i += BLOCK) s[i] = g[i];
@@ -1933,7 +1941,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                 while (m) {
                     const uint32_t b = __builtin_ctz(m);
                     m &= m - 1;
-                    ok &= tmpl_event(sdata, tmpl_l, nT, (uint32_t)((jlb0 + lane) * CHUNK) + b, k++, evt, 0, RB);
+                    ok &= tmpl_event(sdata, tmpl_l, nT, (uint32_t)((jlb0 + lane) * CHUNK) + b, k++, evt, 0);
                 }
             }
             // ... and this lane's own: one walk over its '<' and terminators (32 bytes at a time:
@@ -1950,7 +1958,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                             ++rl;
                             k = 0;
                         } else {
-                            if (rl < RBn) ok &= tmpl_event(sdata, tmpl_l, nT, li + b, k, evt, rl, RB);
+                            if (rl < RBn) ok &= tmpl_event(sdata, tmpl_l, nT, li + b, k, evt, rl);
                             ++k;
                         }
                     }
