@@ -268,7 +268,7 @@ def roofline_of(workload, nbytes, bytes_out, acc, steps, traffic):
     sizing_ms, write_ms, total_ms = acc["count"] / steps, acc["write"] / steps, acc["total"] / steps
 
     def entry(name, alg, ms, tr):
-        ach = alg / (ms * 1e-3) / 1e9
+        ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0  # (a one-pass parse has no sizing pass of its own)
         return {"kernel": name, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
                 "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": tr}
 
