@@ -1,7 +1,7 @@
 """The drop-in on the reference's own header (build container only: the reference tree is not on the GPU
 box and nothing of it is kept here).  tools/patch_public_for_compat.py copies public/_public.h and
 _public.cpp into a temporary directory and puts `#ifndef MDC_PARSE_COMPAT` around the hot-path
-declarations and definitions (what INTEGRATION.md tells a maintainer to do); the patched _public.cpp is
+declarations and definitions (what a maintainer of the toolkit would do by hand); the patched _public.cpp is
 compiled with -DMDC_PARSE_COMPAT, examples/xmltodb_compat.cpp (the calls of tools/xmltodb.cpp:256-268 and
 :492-522 as they stand) is compiled against that _public.h and both are linked with -lmdc_parse.  The
 program is then held to the golden vectors for everything that runs without a GPU, and uses the
