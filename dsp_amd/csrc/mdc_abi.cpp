@@ -204,6 +204,7 @@ struct mdc_parser {
     bool est_valid = false;
     int fused_hold = 0;          // parses that stay with two passes after a one-pass parse had to be repeated
     bool one_pass = false;       // MDC_F_ONE_PASS, or MDC_ONE_PASS in the environment
+    uint32_t spin_limit = FUSED_SPIN_LIMIT;  // (test hook mdc_internal_spin_limit: a tiny limit makes waiting tiles give up)
     int lb_level = 0;   // level that fitted the previous parse
     // workspace
     uint32_t *d_counts = nullptr;
@@ -917,6 +918,7 @@ static int parse_fused(mdc_parser *p, TileParams P, const mdc_outputs *ext, void
     P.cellmap = nullptr;
     P.map_cap = P.map_stride = 0;
     P.fused_totals = p->h_report_dev + REPORT_TOTALS;
+    P.spin_limit = p->spin_limit;
     volatile uint8_t *host_flags = (volatile uint8_t *)(p->h_report + REPORT_FLAGS);
     for (uint32_t i = 0; i < 32; ++i) host_flags[i] = 0;
     for (uint32_t j = 0; j < ncnt; ++j) p->h_totals[j] = 0;
@@ -1480,6 +1482,14 @@ extern "C" int mdc_internal_parser_device(const mdc_parser *p) { return p->dev->
 static bool test_hooks_on() {
     static const bool on = getenv("MDC_TEST_HOOKS") != nullptr;
     return on;
+}
+// Test hook: how many polls a tile of the one-pass parse may spend waiting for one tile in front of it.  With 0 a
+// tile that would have to wait gives up at once: the parse is then repeated in two passes, and no wave waits.
+extern "C" int mdc_internal_spin_limit(mdc_parser *p, unsigned polls) {
+    if (!test_hooks_on()) return fail(MDC_ERR_ARG, "test hooks are off (MDC_TEST_HOOKS is not set)");
+    if (!p) return fail(MDC_ERR_ARG, "NULL argument");
+    p->spin_limit = polls;
+    return MDC_OK;
 }
 extern "C" int mdc_internal_skew_counts(mdc_parser *p, int tile, int col, int delta) {
     if (!test_hooks_on()) return fail(MDC_ERR_ARG, "test hooks are off (MDC_TEST_HOOKS is not set)");

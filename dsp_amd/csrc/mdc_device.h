@@ -217,6 +217,7 @@ struct TileParams {
     uint64_t *pub;          // [ncols+1][ntiles] published counts (PUB_*), zeroed before the launch
     const uint64_t *caps;   // [ncols+1] what the output arrays hold: bytes per column, then rows
     uint64_t *fused_totals; // [ncols+1] totals, written by the last tile (memory of the host)
+    uint32_t spin_limit;    // polls a tile may spend on one tile in front of it before it gives up (FUSED_SPIN_LIMIT)
 };
 
 // ------------------------------------------------------------------------------------------

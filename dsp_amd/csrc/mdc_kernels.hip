@@ -1358,8 +1358,9 @@ __device__ __forceinline__ uint64_t pub_load(const uint64_t *p) {
 // only is added and the window moves on; a tile that has published nothing yet is waited for (the window
 // then begins at it).  Blocks start in index order on each of the chip's dispatchers, so the first tile
 // that has not finished is always resident and the wait ends; should it not, the tile gives up after
-// FUSED_SPIN_LIMIT polls (at once when another tile has given up) and the host parses the input in two passes.
-__device__ __forceinline__ uint64_t fused_lookback(const uint64_t *pubj, uint32_t tile, int lane, const uint32_t *status, bool &giveup) {
+// TileParams::spin_limit polls (at once when another tile has given up) and the host parses the input in two passes.
+__device__ __forceinline__ uint64_t fused_lookback(const uint64_t *pubj, uint32_t tile, int lane, const uint32_t *status, uint32_t spin_limit,
+                                                   bool &giveup) {
     uint64_t excl = 0;
     int64_t hi = (int64_t)tile;
     uint32_t spins = 0;
@@ -1381,7 +1382,7 @@ __device__ __forceinline__ uint64_t fused_lookback(const uint64_t *pubj, uint32_
         hi -= take;
         if (np < 64) {  // tile hi-1 has published nothing yet
             // (once one tile has given up the result is dropped anyway: the others need not wait their turn out)
-            if (++spins > FUSED_SPIN_LIMIT ||
+            if (++spins > spin_limit ||
                 ((spins & 255u) == 0 && (__hip_atomic_load((const gmem_u32 *)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_GIVEUP))) {
                 giveup = true;
                 return excl;
@@ -1880,7 +1881,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         if (FUSED && !rows_done && wave == BLOCK / 64 - 1) {
             bool gu = false;
             uint64_t *pr = P.pub + (uint64_t)ncols * P.ntiles;
-            const uint64_t r0 = SKIP(2048) ? (uint64_t)blockIdx.x * 90 : fused_lookback(pr, blockIdx.x, lane, P.status, gu);
+            const uint64_t r0 = SKIP(2048) ? (uint64_t)blockIdx.x * 90 : fused_lookback(pr, blockIdx.x, lane, P.status, P.spin_limit, gu);
             if (lane == 0) {
                 pub_store(pr + blockIdx.x, PUB_INCL | (r0 + nrec_all));
                 const bool fits = r0 + nrec_all <= P.caps[ncols];
@@ -2484,7 +2485,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         for (uint32_t c = wave; c < ncols; c += BLOCK / 64) {
             bool gu = false;
             uint64_t *pc = P.pub + (uint64_t)c * P.ntiles;
-            const uint64_t base = SKIP(1024) ? (uint64_t)tile * (tiletot[c] - tiletot[c] / 8) : fused_lookback(pc, tile, lane, P.status, gu);
+            const uint64_t base = SKIP(1024) ? (uint64_t)tile * (tiletot[c] - tiletot[c] / 8) : fused_lookback(pc, tile, lane, P.status, P.spin_limit, gu);
             const uint32_t tot = tiletot[c];
             const bool fits = base + tot <= P.caps[c];
             if (lane == 0) {

@@ -161,3 +161,39 @@ def test_many_tiles_against_the_two_pass_parse():
     assert p.timing().one_pass == 1 and p.timing().rows == n
     p.close()
     d.free()
+
+
+def test_tiles_that_may_not_wait_give_up_and_two_passes_follow():
+    """The wait of a tile for the tiles in front of it is bounded.  With the bound set to nothing (a test
+    hook) every tile that would have to wait gives up at once, stores nothing, lets the tiles behind it go
+    on, and the input is parsed again in two passes: the same batch, and no wave is left waiting."""
+    import ctypes
+    import os
+    os.environ["MDC_TEST_HOOKS"] = "1"  # (read when a hook is first called)
+    L = capi.lib()
+    L.mdc_internal_spin_limit.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+    data, n = gen.mind_xml(nbytes=48 << 20)
+    d = capi.DeviceBuffer(data)
+    p = capi.Parser.xml(schema.ZHOBTMIND, flags=ONE)
+    b = p.parse_device(d.ptr, d.n)
+    exp = b.to_host()
+    b.free()
+    capi.check(L.mdc_internal_spin_limit(p.h, 0))
+    gave_up = 0
+    for k in range(4):
+        b = p.parse_device(d.ptr, d.n)
+        got = b.to_host()
+        b.free()
+        t = p.timing()
+        gave_up += t.one_pass_redone
+        assert_batches_equal(got, exp, f"parse {k} with no waiting allowed")
+    assert gave_up >= 1  # (3,072 tiles in flight at once: some tile has to wait)
+    capi.check(L.mdc_internal_spin_limit(p.h, 1 << 16))
+    for k in range(3):
+        b = p.parse_device(d.ptr, d.n)
+        got = b.to_host()
+        b.free()
+        assert_batches_equal(got, exp, "with the usual bound again")
+    assert p.timing().one_pass == 1
+    p.close()
+    d.free()
