@@ -63,7 +63,8 @@ def test_random_schema(port, seed, utc):
     cols, typed = random_schema(rng)
     ty = resolve(cols, typed)
     carry = rng.random() < 0.7
-    endbz = rng.choice(["<endl/>", "<endl/>", "<end/>", "", "##"])
+    endbz = rng.choice(["<endl/>", "<endl/>", "<end/>", "", "##", "<end-of-this-record-and-of-nothing-else/>",
+                        "<e>" * 11])
     damage = rng.choice([0.0, 0.0, 0.02, 0.3, 0.8])
     nrec = rng.choice([40, 400, 3000])
     data = cases.mutated_xml(seed, nrec, cols, endbz=endbz, damage=damage)
@@ -148,7 +149,8 @@ def test_random_delimited(port, seed, utc):
     they do for "aa" and "b b" in these lines; longer: the walk), field counts, clips, conversions and
     trimming over lines from all well-formed to all odd."""
     rng = random.Random(7000 + seed)
-    sep = rng.choice([",", ",", ";", "|", " ", "\t", "~!~", "::", "ab", "aa", "b b", "-.-.", "0.0.0"])
+    sep = rng.choice([",", ",", ";", "|", " ", "\t", "~!~", "::", "ab", "aa", "b b", "-.-.", "0.0.0",
+                      "<-sep->", "0123456789abcdefg", "=" * 16 + ">", "long separator, longer than the header holds"])
     nfields = rng.choice([1, 2, 3, 6, 10, 10, 17, 40])
     ilen = [rng.choice([0, 0, 0, 1, 3, 8, 9, 16, 17, 30]) for _ in range(nfields)]
     typed = [rng.choice([0, 0, 1, 2, 3, 4, 5, 5, 6, 7, 8]) for _ in range(nfields)]
