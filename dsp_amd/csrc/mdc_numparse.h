@@ -25,7 +25,9 @@ enum : uint8_t { T_NONE = 0, T_I32 = 1, T_U32 = 2, T_I64 = 3, T_U64 = 4, T_F64 =
 // strtotime (reference public/_public.cpp:1009-1044): the digits of the text must be exactly
 // fourteen, yyyymmddhh24miss; the fields go to mktime as they are (month - 1, isdst 0), and mktime
 // takes fields out of their ranges arithmetically (month 00 is December of the year before, day
-// 00 the last day of the month before, hour 99 four days on).  For a zone without daylight saving
+// 00 the last day of the month before, hour 99 four days on).  With isdst 0 mktime reads the text
+// as the zone's standard time whether or not daylight saving is in force then, so for a zone whose
+// standard offset is fixed
 // that is plain calendar arithmetic minus the zone's offset (glibc __mktime_internal: year and
 // month folded, days before the month by leap-year table, ydhms difference to 1970).
 // tz_offset = seconds east of UTC.  false when the text does not hold fourteen digits.

@@ -55,9 +55,10 @@ enum {
     MDC_T_BOOL = 7, /* toupper(s)=="TRUE"             -> 0/1                             */
     MDC_T_TIME = 8, /* strtotime(s) (public/_public.cpp:1009-1044): the digits of the text   */
                     /* must be exactly 14, yyyymmddhh24miss -> time_t in the int64 slot, as  */
-                    /* mktime gives it (fields out of range carried over) in a zone without  */
-                    /* daylight saving, mdc_opts.tz_offset seconds east of UTC; not valid    */
-                    /* where strtotime returns -1 for the format                             */
+                    /* mktime gives it (fields out of range carried over) for the zone's     */
+                    /* standard offset, mdc_opts.tz_offset seconds east of UTC (strtotime    */
+                    /* sets tm_isdst to 0, so daylight saving never moves the value); not    */
+                    /* valid where strtotime returns -1 for the format                       */
     MDC_T_DEFAULT = -1 /* number -> F64, date -> I64, char -> NONE                       */
 };
 
@@ -89,7 +90,8 @@ typedef struct mdc_opts {
     const int *typed;    /* per column MDC_T_*; NULL = MDC_T_DEFAULT for every column       */
     unsigned flags;      /* MDC_F_*                                                          */
     int tz_offset;       /* MDC_T_TIME columns: the zone strtotime's mktime would run in,    */
-                         /* seconds east of UTC (28800 for the reference's UTC+8 sites)     */
+                         /* seconds east of UTC (28800 for the reference's UTC+8 sites; the  */
+                         /* standard offset of a zone with daylight saving)                  */
 } mdc_opts;
 
 enum {

@@ -21,7 +21,7 @@ from oracle import oracle_lib as ol  # noqa: E402
 def main():
     ref = ol.load("reference")
     out = []
-    for tz, off in tc.ZONES:
+    for tz, off in tc.STRTOTIME_ZONES:
         os.environ["TZ"] = tz
         time.tzset()
         rows = []

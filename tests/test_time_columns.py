@@ -1,7 +1,9 @@
 """Typed time columns (MDC_T_TIME): strtotime of the reference (public/_public.cpp:1009-1044).
 The CPU checker calls libc's mktime in the process's time zone, the reference build calls the
-reference's strtotime; the GPU computes the calendar arithmetic itself for a zone without daylight
-saving given as an offset.  Zones are set with POSIX TZ strings (no zone files needed)."""
+reference's strtotime; the GPU computes the calendar arithmetic itself for a zone given as an offset.
+strtotime sets tm_isdst to 0 (:1039), and mktime then reads the text as the zone's STANDARD time in
+summer as in winter, so a zone with daylight saving is its standard offset too (STRTOTIME_ZONES).
+Zones are set with POSIX TZ strings (no zone files needed)."""
 import os
 import random
 import time
@@ -14,8 +16,14 @@ from dsp_amd.schema import Col
 from oracle import oracle_lib as ol
 
 ZONES = [("UTC0", 0), ("CST-8", 28800), ("EST5", -18000), ("IST-5:30", 19800)]
+# zones with daylight saving: for strtotime only (timetostr's localtime does move the clock in summer)
+# (a southern rule such as AEST-10AEDT,M10.1.0,M4.1.0/3 is its standard offset as well from 1962 on; for earlier
+# years glibc's mktime gives up there (-1) when tm_isdst is 0, which an offset does not reproduce)
+DST_ZONES = [("EST5EDT,M3.2.0,M11.1.0", -18000), ("CET-1CEST,M3.5.0,M10.5.0/3", 3600)]
+STRTOTIME_ZONES = ZONES + DST_ZONES
 
-PROBES = [b"20240519162800", b"2024-05-19 16:28:00", b"2024/05/19 16:28:00.000"[:19], b"19700101000000", b"19691231235959",
+PROBES = [b"20240519162800", b"20240314023000", b"20240310023000", b"20241103013000", b"20240331023000", b"20241027023000",
+          b"20240701120000", b"20240101120000", b"20241006023000", b"20240407023000", b"2024-05-19 16:28:00", b"2024/05/19 16:28:00.000"[:19], b"19700101000000", b"19691231235959",
           b"00000000000000", b"00010101000000", b"20240229000000", b"20230229000000", b"21000229000000", b"20000229235959",
           b"20240019000000", b"20241319000000", b"20249919000000", b"20240500000000", b"20240532000000", b"20240519250000",
           b"20240519996199", b"99991231235959", b"2024051916280", b"202405191628000", b"", b"x", b"1e14",
@@ -53,7 +61,7 @@ def random_times(seed, n):
     return out
 
 
-@pytest.mark.parametrize("zone", ZONES, indirect=True, ids=[z[0] for z in ZONES])
+@pytest.mark.parametrize("zone", STRTOTIME_ZONES, indirect=True, ids=[z[0] for z in STRTOTIME_ZONES])
 def test_port_equals_reference(zone, port, reference):
     for t in PROBES + random_times(3, 3000):
         assert port.convert(t, ol.T_TIME) == reference.convert(t, ol.T_TIME), t
@@ -100,7 +108,7 @@ def model(text: bytes, tz_offset: int):
     return (((days * 24 + hour) * 60 + mi) * 60 + sec - tz_offset) & 0xFFFFFFFFFFFFFFFF
 
 
-@pytest.mark.parametrize("zone", ZONES, indirect=True, ids=[z[0] for z in ZONES])
+@pytest.mark.parametrize("zone", STRTOTIME_ZONES, indirect=True, ids=[z[0] for z in STRTOTIME_ZONES])
 def test_calendar_arithmetic_equals_mktime(zone, port):
     for t in PROBES + random_times(5, 20000):
         ok, v = port.convert(t, ol.T_TIME)
@@ -126,7 +134,7 @@ def time_file(seed, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("zone", ZONES, indirect=True, ids=[z[0] for z in ZONES])
+@pytest.mark.parametrize("zone", STRTOTIME_ZONES, indirect=True, ids=[z[0] for z in STRTOTIME_ZONES])
 def test_gpu_time_columns(zone, port):
     from util import assert_batches_equal
     data = time_file(9, 6000)
@@ -177,7 +185,7 @@ COLS_PLAIN = [Col("obtid", "char", 10), Col("ddatetime", "date", 14), Col("uptti
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("zone", ZONES, indirect=True, ids=[z[0] for z in ZONES])
+@pytest.mark.parametrize("zone", STRTOTIME_ZONES, indirect=True, ids=[z[0] for z in STRTOTIME_ZONES])
 def test_gpu_plain_time_cells(zone, port):
     from util import assert_batches_equal
     data = compact_file(31, 20000)
