@@ -265,6 +265,7 @@ static const OutPtrs g_no_out{};  // the sizing pass writes to no output array
 
 // five blocks per CU fit when a block asks for at most this much LDS (measured: 31.6 KB does, 32.2 KB does not)
 static const uint32_t LDS_FIVE_BLOCKS = 31 * 1024 + 256;
+static const uint32_t LDS_PER_CU = 160 * 1024;  // what one block may ask for at most
 
 // lean = the sizing pass of tagged input: it keeps no event list, stages no cells and needs no
 // output pointers, which is worth a sixth block per CU
@@ -313,7 +314,7 @@ static void compute_layout(uint32_t ncols, uint32_t npat, uint32_t words, uint32
         L.total = o;
         L.RB = RB;
         if (o <= (lean ? LDS_SIX_BLOCKS : LDS_FIVE_BLOCKS) || RB <= 8) break;
-        if (RB > 64 && lbmax > 1536) break;  // the larger look-behind configurations trade occupancy
+        if (RB > 64 && lbmax > 1536 && o <= LDS_PER_CU) break;  // the larger look-behind configurations trade occupancy
         RB = RB > 16 ? RB - 8 : RB / 2;
     }
 }
@@ -349,7 +350,7 @@ static void compute_emit_layout(uint32_t ncols, uint32_t words, uint32_t lbmax, 
         L.total = o;
         L.RB = RB;
         if (o <= LDS_FIVE_BLOCKS || RB <= 8) break;
-        if (RB > 64 && lbmax > 1536) break;
+        if (RB > 64 && lbmax > 1536 && o <= LDS_PER_CU) break;
         RB = RB > 16 ? RB - 8 : RB / 2;
     }
 }
@@ -583,8 +584,8 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
         compute_emit_layout(ncols, p->words, LB_LEVELS[lv], p->LEs[lv]);
         compute_emit_layout(ncols, p->words, LB_LEVELS[lv], p->LEd[lv], true);
         compute_layout(ncols, npat, p->words, ((const SchemaHdr *)p->blob.data())->p10_off, LB_LEVELS[lv], p->LSs[lv], npat != 0, true);
-        if (p->Ls[lv].total > 160 * 1024)
-            return fail(MDC_ERR_ARG, "schema too large for LDS (%u bytes)", p->Ls[lv].total);
+        for (const LdsLayout *L : {&p->Ls[lv], &p->LEs[lv], &p->LEd[lv], &p->LSs[lv]})
+            if (L->total > LDS_PER_CU) return fail(MDC_ERR_ARG, "schema too large for LDS (%u bytes)", L->total);
     }
     compute_fused_layout(ncols, npat, p->words, (uint32_t)p->blob.size(), LB_LEVELS[0], p->LF);
     return MDC_OK;

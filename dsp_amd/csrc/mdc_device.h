@@ -18,7 +18,7 @@ constexpr int CHUNK = 16;                                // bytes per lane per s
 constexpr int DATA_SLACK = 64;                           // readable bytes past the image
 constexpr int LB_FIRST = 512;                            // first look-behind window
 constexpr int LB_STEP = BLOCK * CHUNK;                   // later windows
-constexpr int MAX_COLS = 128;
+constexpr int MAX_COLS = 256;
 constexpr int MAX_ENDBZ = 32;       // end marks and separators up to these lengths lie in the schema header ...
 constexpr int MAX_SEP = 16;
 constexpr int MAX_LONG_TEXT = 255;  // ... longer ones (up to this) in front of the table of powers of ten, see long_text

@@ -187,7 +187,7 @@ enum {
     MS_STAGE = 18,  // bytes of the staging area handed out so far
     MS_ODD = 19,    // the tile does not take the straight-line write: left to the full write kernel
     MS_ROWOK = 20,  // the tile's rows fit the output arrays
-    MS_FWORD = 24,  // up to 4 words: found bits of a row that follows the template
+    MS_FWORD = 24,  // up to 8 words: found bits of a row that follows the template
     MS_XCOUNT = 32
 };
 

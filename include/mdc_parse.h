@@ -143,7 +143,7 @@ const char *mdc_last_error(void);
  * splitbuffer (tools/xmltodb.cpp:492-522), i.e. getxmlbuffer(xml,colname,temp,collen)
  * (public/_public.cpp:461-481) + picknumber(temp,temp,..) (public/_public.cpp:178-204) +
  * vcolvalue[i]=temp.c_str() for every column of the schema.  Limits (MDC_ERR_ARG beyond them; the
- * reference has none): column names without '>' and '\n', at most 128 columns, an end mark
+ * reference has none): column names without '>' and '\n', at most 256 columns, an end mark
  * (opts->endbz) of at most 255 bytes without '\n'.  (An end mark that holds a newline may overlap the
  * terminator in front of it, and cifile::readline only matches it within the record gathered so far:
  * the split would then be a left-to-right decision over the whole file.) */
@@ -177,7 +177,7 @@ int mdc_parse_file(mdc_parser *p, const char *path, mdc_batch **out);
  * pointers) lies in a static device array of MDC_NOALLOC_SCRATCH_BYTES that every GPU the
  * library runs on holds until the process ends.
  *   limit    per 16 KiB of input, 16 x columns + 52 bytes must fit the array: about 140 MiB of
- *            input with 11 columns, 15 MiB with 128; beyond that MDC_ERR_TOO_LARGE
+ *            input with 11 columns, 15 MiB with 128, 8 MiB with 256; beyond that MDC_ERR_TOO_LARGE
  *            (use mdc_parse_device, or parse the input in parts)
  *   outputs  per column: rows_cap + 1 u32 offsets, bytes_cap bytes of cells, and for a typed
  *            column rows_cap u64 values; rows_cap x mdc_batch_words_per_row words each of valid

@@ -43,7 +43,7 @@ def test_schema_validation_happens_before_the_device_is_needed():
         capi.Parser.csv("", 3)
     assert e.value.code == capi.MDC_ERR_ARG
     with pytest.raises(capi.MdcError) as e:
-        capi.Parser.xml([schema.Col("a", "char", 0)] * 200)
+        capi.Parser.xml([schema.Col("a", "char", 0)] * 257)
     assert e.value.code == capi.MDC_ERR_ARG
 
 

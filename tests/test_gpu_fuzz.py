@@ -19,8 +19,8 @@ SEEDS = range(int(os.environ.get("MDC_FUZZ_FIRST", "0")), int(os.environ.get("MD
 pytestmark = pytest.mark.gpu
 
 
-def random_schema(rng):
-    n = rng.choice([1, 2, 3, 5, 8, 11, 17, 30])
+def random_schema(rng, n=None):
+    n = n or rng.choice([1, 2, 3, 5, 8, 11, 17, 30])
     names = set()
     while len(names) < n:
         k = rng.choice([1, 1, 2, 3, 5, 6, 7, 8, 9, 12, 15, 16, 17, 24, 31])
@@ -78,6 +78,28 @@ def test_random_schema(port, seed, utc):
         other = cases.mutated_xml(seed + 500, nrec // 2 + 1, cols, endbz=endbz, damage=min(1.0, damage * 2 + 0.01))
         assert_batches_equal(p.parse_host(other).to_host(), port.parse_xml(other, cols, typed=ty, endbz=endbz, carry=carry),
                              f"seed {seed} other")
+        assert_batches_equal(p.parse_host(data).to_host(), exp, f"seed {seed} again")
+    finally:
+        p.close()
+
+
+@pytest.mark.parametrize("seed", SEEDS[:12])
+def test_random_wide_schema(port, seed, utc):
+    """Schemas of more than 128 columns (one pointer table's worth): records of several KiB, so tiles of a few
+    records, records across tiles and, where the cells are long, records beyond every look-behind."""
+    rng = random.Random(7000 + seed)
+    cols, typed = random_schema(rng, rng.choice([129, 160, 200, 255, 256]))
+    ty = resolve(cols, typed)
+    carry = rng.random() < 0.7
+    endbz = rng.choice(["<endl/>", "<endl/>", "", "##"])
+    damage = rng.choice([0.0, 0.02, 0.3])
+    nrec = rng.choice([12, 120, 600])
+    data = cases.mutated_xml(seed, nrec, cols, endbz=endbz, damage=damage)
+    print("seed", seed, "ncols", len(cols), "carry", carry, "endbz", repr(endbz), "damage", damage, "bytes", len(data), flush=True)
+    exp = port.parse_xml(data, cols, typed=ty, endbz=endbz, carry=carry)
+    p = capi.Parser.xml(cols, typed=ty, endbz=endbz, carry=carry)
+    try:
+        assert_batches_equal(p.parse_host(data).to_host(), exp, f"seed {seed}")
         assert_batches_equal(p.parse_host(data).to_host(), exp, f"seed {seed} again")
     finally:
         p.close()

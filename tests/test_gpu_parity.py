@@ -2,6 +2,7 @@
 vectors.  Bit-exact for every output (cell bytes, offsets, record offsets, masks, typed values)."""
 import ctypes
 import os
+import random
 
 import numpy as np
 import pytest
@@ -498,7 +499,7 @@ def test_tag_template_follows_the_input(port):
     p.close()
 
 
-@pytest.mark.parametrize("ncols", [20, 33, 64, 128])
+@pytest.mark.parametrize("ncols", [20, 33, 64, 128, 129, 200, 256])
 def test_wide_schemas_with_and_without_room_for_the_template(port, ncols):
     """Regular records under schemas of growing width: the template's entries and column plan fit
     the sizing pass's LDS for the narrow ones only; beyond that (and beyond 64 events per record)
@@ -511,6 +512,46 @@ def test_wide_schemas_with_and_without_room_for_the_template(port, ncols):
     data = b"<data>\n" + b"".join(recs) + b"</data>\n"
     got = gpu_xml(data, cols)
     assert_batches_equal(got, port.parse_xml(data, cols), "ncols=%d" % ncols)
+
+
+def test_wide_schema_with_records_longer_than_a_tile(port):
+    """256 columns with cells of 20 to 200 bytes: every record is some 30 KiB, longer than a tile and than
+    every look-behind, so all of them go to the long-record kernel; short records in between."""
+    rng = random.Random(256)
+    cols = [Col("k%d" % i, ("char", "number", "date")[i % 3], (0, 22, 14)[i % 3]) for i in range(256)]
+    recs = []
+    for r in range(24):
+        short = r % 5 == 4
+        recs.append(b"".join(b"<k%d>%s</k%d>" % (i, (b"%d" % rng.randrange(10 ** 9)) * (1 if short else rng.randrange(2, 20)), i)
+                             for i in range(256) if rng.random() < 0.9) + b"<endl/>\n")
+    data = b"".join(recs)
+    assert max(map(len, recs)) > 20000
+    got = gpu_xml(data, cols)
+    assert_batches_equal(got, port.parse_xml(data, cols), "256 columns, long records")
+
+
+@pytest.mark.parametrize("sep", [",", "~!~"])
+@pytest.mark.parametrize("nfields", [129, 256])
+def test_wide_delimited_records(port, nfields, sep):
+    """More fields than one pointer table of 128 held: lines with fewer fields than the schema, with exactly as
+    many and with more, cells of every typed kind, fields cut to a length."""
+    rng = random.Random(nfields)
+    typed = [ALL_T[i % len(ALL_T)] for i in range(nfields)]
+    ilen = [(0, 0, 3, 0, 7)[i % 5] for i in range(nfields)]
+    lines = []
+    for r in range(1500):
+        k = rng.choice([nfields, nfields, nfields, nfields - 1, nfields + 3, rng.randrange(1, nfields)])
+        cells = []
+        for i in range(k):
+            kind = rng.random()
+            cells.append(str(rng.randrange(-10 ** 6, 10 ** 6)) if kind < 0.5 else "%.3f" % rng.uniform(-1e3, 1e3) if kind < 0.7
+                         else "" if kind < 0.8 else rng.choice(["true", " x ", "20240519162800", "abc def", "-"]))
+        lines.append(sep.join(cells))
+    data = ("\n".join(lines) + "\n").encode()
+    for bdel in (False, True):
+        got = gpu_csv(data, sep, nfields, ilen=ilen, typed=typed, bdelspace=bdel)
+        exp = port.parse_csv(data, sep, nfields, ilen=ilen, typed=typed, bdelspace=bdel)
+        assert_batches_equal(got, exp, f"{nfields} fields {sep!r} {bdel}")
 
 
 @pytest.mark.parametrize("nbytes", [(32 << 20) - 5, (32 << 20) + 1, (56 << 20) + 4097, 100 << 20])
