@@ -2959,7 +2959,8 @@ __global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P, 
                 m = keep;
             }
             cand[tid] = (uint16_t)m;
-            __syncthreads();
+            // (a window without a mark, as every window of one very long field is, costs no walk)
+            if (!__syncthreads_or(m != 0)) continue;
             if (tid == 0) {
                 for (int t = 0; t < BLOCK && nsep < ncols; ++t) {
                     uint32_t x = cand[t];
@@ -3052,12 +3053,18 @@ __global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P, 
             if (tid == 0) sh[2] = len;
             __syncthreads();
             uint32_t cut = len;
-            for (uint32_t k0 = 0; k0 < len && cut == len; k0 += BLOCK * CHUNK) {
-                for (uint32_t k = k0 + tid * CHUNK; k < k0 + (tid + 1) * CHUNK && k < len; ++k)
-                    if (data[src + k] == 0) {
-                        atomicMin(&sh[2], k);
+            const int64_t send = src + len;
+            for (int64_t cb = src & ~(int64_t)15; cb < send && cut == len; cb += BLOCK * CHUNK) {
+                const int64_t pos = cb + (int64_t)tid * CHUNK;
+                uint32_t z = pos < send ? mask16_eq(gchunk(data, n, pos), 0u) : 0u;
+                while (z) {
+                    const int64_t q = pos + __builtin_ctz(z);
+                    z &= z - 1;
+                    if (q >= src && q < send) {
+                        atomicMin(&sh[2], (uint32_t)(q - src));
                         break;
                     }
+                }
                 __syncthreads();
                 cut = sh[2];
                 __syncthreads();  // (everyone has read the word before the next window may lower it)
@@ -3067,7 +3074,14 @@ __global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P, 
         // the filtered length, and with WRITE the surviving bytes in order
         uint8_t *dst = WRITE ? O.bytes[c] + tb[c] : nullptr;
         uint32_t flen = 0;  // (block-uniform running total)
-        for (uint32_t k0 = 0; k0 < len; k0 += BLOCK * CHUNK) {
+        if (lvl == LVL_CHAR) {
+            // text keeps every byte (the only cells that grow without bound: numbers and dates are clipped to
+            // their column's length before the filter): nothing to count, a plain copy
+            if (WRITE)
+                for (uint32_t k = tid; k < len; k += BLOCK) dst[k] = data[src + k];
+            flen = len;
+        }
+        for (uint32_t k0 = 0; k0 < len && lvl != LVL_CHAR; k0 += BLOCK * CHUNK) {
             const uint32_t kb = k0 + tid * CHUNK;
             uint32_t cnt = 0;
             uint8_t keep[CHUNK];
