@@ -32,6 +32,7 @@ hipError_t launch_tile_kernel(int mode, const TileParams &P, const OutPtrs &O, h
 hipError_t launch_emit_kernel(const TileParams &P, const OutPtrs &O, hipStream_t stream);
 hipError_t launch_template_kernel(const TileParams &P, hipStream_t stream);
 hipError_t launch_long_records(bool write, const TileParams &P, const OutPtrs &O, uint32_t count, hipStream_t stream);
+hipError_t launch_mark_overlap(const TileParams &P, hipStream_t stream);
 uint32_t scan_segments(uint32_t ntiles);
 hipError_t launch_scan_tiles(const uint32_t *counts, uint64_t *base, uint32_t ntiles, uint32_t ncnt, uint64_t *report,
                              const uint64_t *status, uint32_t report_status, hipStream_t stream);
@@ -204,6 +205,7 @@ struct mdc_parser {
     bool est_valid = false;
     int fused_hold = 0;          // parses that stay with two passes after a one-pass parse had to be repeated
     bool one_pass = false;       // MDC_F_ONE_PASS, or MDC_ONE_PASS in the environment
+    bool mark_nl = false;        // the end mark holds a newline: no template, and a pass that looks for overlapping marks
     uint32_t spin_limit = FUSED_SPIN_LIMIT;  // (test hook mdc_internal_spin_limit: a tiny limit makes waiting tiles give up)
     int lb_level = 0;   // level that fitted the previous parse
     // workspace
@@ -410,8 +412,9 @@ static int build_blob(mdc_parser *p, const char *endbz, int carry, const char *s
     if (el > MAX_LONG_TEXT) return fail(MDC_ERR_ARG, "endbz longer than %d bytes", MAX_LONG_TEXT);
     // (An end mark that holds a newline may overlap the terminator in front of it, and whether it counts then
     // depends on where the record began: cifile::readline matches the mark within the record it has gathered
-    // so far.  That makes the split a left-to-right decision over the whole file, which this parser does not take.)
-    if (memchr(endbz, '\n', el)) return fail(MDC_ERR_ARG, "endbz must not contain a newline");
+    // so far.  Inputs in which no two occurrences of the mark overlap need no such left-to-right decision; a
+    // pass over the input looks for an overlap and the parse is refused where there is one.)
+    p->mark_nl = memchr(endbz, '\n', el) != nullptr;
     size_t sl = 0;
     if (p->mode == MODE_CSV) {
         sl = strlen(sep);
@@ -797,6 +800,9 @@ static int ensure_cellmap(mdc_parser *p, size_t n, size_t ntiles) {
 static int status_to_error(uint32_t st) {
     if (st & ST_RECORD_TOO_LONG)
         return fail(MDC_ERR_RECORD_TOO_LONG, "a record of 2 GiB or more (the reference's own positions are ints)");
+    if (st & ST_MARK_OVERLAP)
+        return fail(MDC_ERR_ARG, "two occurrences of the end mark overlap in this input (a newline inside one follows another): "
+                                 "which of them ends a record is a left-to-right decision this parser does not take");
     if (st) return fail(MDC_ERR_INTERNAL, "kernel status %#x", st);
     return MDC_OK;
 }
@@ -1105,6 +1111,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         P.cellmap = nullptr;
         P.map_cap = P.map_stride = 0;
     }
+    if (p->mark_nl) P.use_tmpl = 0;  // (a template's tag texts hold no newline; every tile takes the table lookup)
     for (int t : p->typed)
         if (t == MDC_T_TIME || t == MDC_T_F32) P.special_cols = 1;
 #ifdef MDC_ABLATE
@@ -1139,6 +1146,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         P.L = p->LSs[p->lb_level];
         HIP_TRY(hipMemsetAsync(p->d_status, 0, 16, s));  // status word, tiles that left the template, long records
         HIP_TRY(hipEventRecord(p->ev[0], s));
+        if (p->mark_nl) HIP_TRY(launch_mark_overlap(P, s));
         const bool build_tmpl = P.use_tmpl && !p->tmpl_valid && ntiles;
         if (build_tmpl) HIP_TRY(launch_template_kernel(P, s));
         P.schema_bytes = P.p10_off;  // (the sizing pass converts nothing: the schema without the powers of ten)

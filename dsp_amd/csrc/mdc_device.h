@@ -65,6 +65,7 @@ enum : uint32_t {
     ST_UNMAPPED = 8u,  // a tile of the sizing pass left no cell map: the write pass re-derives it
     ST_OVERFLOW = 16u, // one-pass parse: an output array is smaller than what the input holds
     ST_GIVEUP = 32u,   // one-pass parse: a tile waited too long for the tiles in front of it
+    ST_MARK_OVERLAP = 64u,  // an end mark that holds a newline: two of its occurrences overlap in the input
 };
 
 // One-pass parse: what a tile publishes for the tiles behind it, one 64-bit word per counter (bytes of

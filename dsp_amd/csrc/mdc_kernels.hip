@@ -3127,6 +3127,41 @@ __global__ __launch_bounds__(BLOCK) void long_record_kernel(const TileParams P, 
     }
 }
 
+// An end mark that holds a newline.  cifile::readline (reference public/_public.cpp:878-888) looks for the mark at
+// the end of the record gathered so far, so a newline that follows the mark ends a record only if the whole mark
+// lies behind the previous terminator.  The kernels take every newline that follows the mark's text; that is the
+// same thing unless two such places lie within one mark's length of each other, i.e. unless a newline inside one
+// occurrence of the mark itself follows another occurrence.  This pass looks for such a pair (one read of the
+// input, only for such marks) and raises ST_MARK_OVERLAP: the parse is then refused instead of split wrongly.
+__global__ __launch_bounds__(BLOCK) void mark_overlap_kernel(const uint8_t *data, uint64_t nbytes, const uint8_t *schema,
+                                                             uint32_t *status) {
+    const SchemaHdr *H = (const SchemaHdr *)schema;
+    const int64_t n = (int64_t)nbytes;
+    const int el = (int)H->endbz_len;
+    const uint8_t *mark = endbz_text(H);
+    bool found = false;
+    for (int64_t pos = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * CHUNK; pos < n; pos += (int64_t)gridDim.x * BLOCK * CHUNK) {
+        uint32_t nl = mask16_eq(gchunk(data, n, pos), 0x0A0A0A0Au);
+        while (nl) {
+            const int64_t p = pos + __builtin_ctz(nl);
+            nl &= nl - 1;
+            if (p >= n || !gterm(data, H, p)) continue;
+            for (int j = 0; j < el; ++j)  // the newlines inside this occurrence: does one of them follow the mark as well?
+                if (mark[j] == '\n' && gterm(data, H, p - el + j)) found = true;
+        }
+    }
+    if (found) atomicOr(status, ST_MARK_OVERLAP);
+}
+
+hipError_t launch_mark_overlap(const TileParams &P, hipStream_t stream) {
+    if (P.n == 0) return hipSuccess;
+    const uint64_t chunks = (P.n + CHUNK - 1) / CHUNK;
+    uint64_t blocks = (chunks + BLOCK - 1) / BLOCK;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(mark_overlap_kernel, dim3((uint32_t)blocks), dim3(BLOCK), 0, stream, P.data, (uint64_t)P.n, P.schema, P.status);
+    return hipGetLastError();
+}
+
 hipError_t launch_long_records(bool write, const TileParams &P, const OutPtrs &O, uint32_t count, hipStream_t stream) {
     if (count == 0) return hipSuccess;
     const uint32_t lds = ((P.schema_bytes + 15) & ~15u) + 5 * P.ncols * 4 + 64;

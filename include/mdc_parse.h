@@ -144,9 +144,11 @@ const char *mdc_last_error(void);
  * (public/_public.cpp:461-481) + picknumber(temp,temp,..) (public/_public.cpp:178-204) +
  * vcolvalue[i]=temp.c_str() for every column of the schema.  Limits (MDC_ERR_ARG beyond them; the
  * reference has none): column names without '>' and '\n', at most 256 columns, an end mark
- * (opts->endbz) of at most 255 bytes without '\n'.  (An end mark that holds a newline may overlap the
- * terminator in front of it, and cifile::readline only matches it within the record gathered so far:
- * the split would then be a left-to-right decision over the whole file.) */
+ * (opts->endbz) of at most 255 bytes.  An end mark that holds a newline is taken unless two of its
+ * occurrences overlap in the input (a newline inside one follows another: cifile::readline only matches
+ * the mark within the record gathered so far, so which of the two ends a record is a left-to-right
+ * decision over the whole file); such an input is refused with MDC_ERR_ARG by the parse, which looks for
+ * it in a pass of its own.  Inputs with such a mark are parsed without the tag template. */
 int mdc_parser_create_xml(const mdc_col *cols, int ncols, const mdc_opts *opts, mdc_parser **out);
 
 /* Replaces, per line: cifile::readline(buf) + ccmdstr::splittocmd(buf,sep,bdelspace)

@@ -26,8 +26,9 @@
  * One difference in failure handling: there is no CPU path for the record split, so open() fails
  * (as for a file that cannot be opened: _xmltodb() then returns 5 and the file goes to the error
  * directory, tools/xmltodb.cpp:256-261, :187-204) when no usable GPU is present, and readline()
- * returns false with errcode() set when endbz holds a newline or more than 255 bytes, which the GPU
- * record splitter does not take.  Header only; link with -lmdc_parse.
+ * returns false with errcode() set when endbz holds more than 255 bytes, or holds a newline and two of
+ * its occurrences in the file overlap, which the GPU record splitter does not take.  Header only; link
+ * with -lmdc_parse.
  */
 #ifndef MDC_PUBLIC_COMPAT_H
 #define MDC_PUBLIC_COMPAT_H
@@ -474,8 +475,8 @@ class cifile {
         if (m_parser) mdc_parser_destroy(m_parser);
         m_parser = nullptr;
         m_split = false;
-        if (endbz.size() > 255 || endbz.find('\n') != std::string::npos || endbz.find('\0') != std::string::npos)
-            return fail(MDC_ERR_ARG, "readline: an end mark with a newline, a NUL or more than 255 bytes is not supported");
+        if (endbz.size() > 255 || endbz.find('\0') != std::string::npos)
+            return fail(MDC_ERR_ARG, "readline: an end mark with a NUL or more than 255 bytes is not supported");
         /* only the record offsets are wanted: the record split alone (the one column a schema must have
          * gets no cells) */
         mdc_col col;

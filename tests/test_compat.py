@@ -167,5 +167,21 @@ def test_file_loop_over_a_large_file_and_the_missing_file(exe, tmp_path, port):
     rc, out, err = _run(exe, ["xml", str(tmp_path / "none.xml"), _spec(schema.ZHOBTMIND)])
     assert rc == 5
     # an end mark the GPU splitter does not take is refused, not guessed at
-    rc, out, err = _run(exe, ["xml", str(f), _spec(schema.ZHOBTMIND), b"a\nb".hex()])
+    rc, out, err = _run(exe, ["xml", str(f), _spec(schema.ZHOBTMIND), (b"m" * 256).hex()])
     assert rc == 2 and "end mark" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mark", [b"<endl/>\n<next/>", b"\n", b"e\n"])
+def test_file_loop_with_an_end_mark_that_holds_a_newline(exe, tmp_path, port, mark):
+    # cifile::readline gathers lines until the text ends with the mark (public/_public.cpp:872-889)
+    cols = schema.ZHOBTMIND[:3]
+    recs = [b"<obtid>%d</obtid><ddatetime>20240519%06d</ddatetime><t>%d.5\nx</t>" % (50000 + i, i, i % 40) + mark + b"\n" for i in range(4000)]
+    data = b"<data>" + b"".join(recs) + b"</data>\n"
+    f = tmp_path / "nl.xml"
+    f.write_bytes(data)
+    exp = port.parse_xml(data, cols, endbz=mark.decode())
+    assert exp.rows == 4000
+    rc, out, err = _run(exe, ["xml", str(f), _spec(cols), mark.hex()])
+    assert rc == 0, err
+    assert out[:-1] == _expected_rows(exp)

@@ -91,7 +91,7 @@ def test_random_wide_schema(port, seed, utc):
     cols, typed = random_schema(rng, rng.choice([129, 160, 200, 255, 256]))
     ty = resolve(cols, typed)
     carry = rng.random() < 0.7
-    endbz = rng.choice(["<endl/>", "<endl/>", "", "##"])
+    endbz = rng.choice(["<endl/>", "<endl/>", "", "##", "<end\n/>", "##\n"])  # (marks with a newline that cannot overlap themselves)
     damage = rng.choice([0.0, 0.02, 0.3])
     nrec = rng.choice([12, 120, 600])
     data = cases.mutated_xml(seed, nrec, cols, endbz=endbz, damage=damage)

@@ -997,3 +997,57 @@ def test_long_end_marks(port, marklen):
     got = gpu_xml(data[: len(data) // 2] + big + data[len(data) // 2:], cases.SMALL, endbz=mark)
     exp = port.parse_xml(data[: len(data) // 2] + big + data[len(data) // 2:], cases.SMALL, endbz=mark)
     assert_batches_equal(got, exp, f"end mark of {marklen} bytes, long record")
+
+
+NEWLINE_MARKS = ["<endl/>\n<next/>", "a\nb", "\n", "x\n", "\n##", "<e>\n\n", "<end of\nthis record\nand of nothing else/>" * 3]
+
+
+@pytest.mark.parametrize("mark", NEWLINE_MARKS, ids=[repr(m)[:24] for m in NEWLINE_MARKS])
+def test_end_marks_that_hold_a_newline(port, mark):
+    """cifile::readline (public/_public.cpp:872-889) gathers lines until the gathered text ends with the mark, so a
+    mark may hold newlines (even end with one, which then takes an empty line behind it).  Records with parts of the
+    mark, with newlines of their own and with the mark followed by text; through the delimited mode, a long record
+    and the record split alone as well."""
+    rng = random.Random(len(mark))
+    recs = []
+    for i in range(5000):
+        body = "<a>%d</a><ab>%s</ab><b>%d.25</b>" % (i, "v\nw" if i % 7 == 0 else "v", i % 977)
+        if i % 13 == 0:
+            body += mark[:-1] + "Q\nz"       # (the mark cut short, then other text: ends nothing)
+        if i % 17 == 0:
+            body += mark + "x\nz"            # (the mark with text behind it: ends nothing)
+        if i % 19 == 0:
+            body += "y\ny" * rng.randrange(1, 3)  # (newlines of the record's own, with text on both sides)
+        recs.append(body + mark + "\n")
+    data = ("".join(recs) + "<a>tail</a>" + mark).encode()
+    exp = port.parse_xml(data, cases.SMALL, endbz=mark)
+    assert exp.rows >= 5000, exp.rows
+    got = gpu_xml(data, cases.SMALL, endbz=mark)
+    assert_batches_equal(got, exp, f"end mark {mark!r}")
+    # the same through a long record, and without the carry-forward
+    half = len("".join(recs[:2500]).encode())
+    big = data[:half] + ("<a>1</a><ab>" + "j\n" * 20000 + "</ab>" + mark + "\n").encode() + data[half:]
+    assert_batches_equal(gpu_xml(big, cases.SMALL, endbz=mark, carry=False), port.parse_xml(big, cases.SMALL, endbz=mark, carry=False),
+                         f"end mark {mark!r}, long record")
+    # the record split alone (what cifile::readline of the compat header asks for)
+    p = capi.Parser.xml(cases.SMALL[:1], endbz=mark, flags=capi.MDC_F_RECORDS_ONLY)
+    b = p.parse_host(data).to_host()
+    p.close()
+    assert b.rows == exp.rows and np.array_equal(b.rec_off, exp.rec_off)
+
+
+def test_overlapping_end_marks_are_refused(port):
+    """Two occurrences of a mark that overlap (a newline inside the second follows the first): cifile::readline
+    takes the first and starts the next record behind it, so the second ends nothing.  That is a left-to-right
+    decision; the parser finds such an input and refuses it instead of splitting it wrongly."""
+    for mark, bad in (("\n", b"<a>1</a>\n\n\n<a>2</a>\n\n"), ("a\na", b"<a>1</a>a\na\na\n<a>2</a>a\na\n"),
+                      ("q\nq", b"<a>1</a>q\nq\n" * 3000 + b"<a>2</a>q\nq\nq\n" + b"<a>3</a>q\nq\n" * 3000)):
+        assert port.parse_xml(bad, cases.SMALL, endbz=mark).rows >= 2  # (the reference's answer exists)
+        p = capi.Parser.xml(cases.SMALL, endbz=mark)
+        with pytest.raises(capi.MdcError) as e:
+            p.parse_host(bad)
+        assert e.value.code == capi.MDC_ERR_ARG and "overlap" in str(e.value)
+        # the parser stays usable
+        good = b"<a>1</a>" + mark.encode() + b"\n<a>2</a>" + mark.encode() + b"\n"
+        assert_batches_equal(p.parse_host(good).to_host(), port.parse_xml(good, cases.SMALL, endbz=mark), f"after a refusal, {mark!r}")
+        p.close()
