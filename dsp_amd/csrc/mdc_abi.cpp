@@ -1754,7 +1754,7 @@ extern "C" int mdc_formatter_create(const char *const *fieldname, const int *fie
                                     mdc_formatter **out) {
     if (!out) return fail(MDC_ERR_ARG, "out is NULL");
     *out = nullptr;
-    if (!fieldname || nfields < 1 || nfields > 128) return fail(MDC_ERR_ARG, "1..128 fields required");
+    if (!fieldname || nfields < 1 || nfields > 256) return fail(MDC_ERR_ARG, "1..256 fields required");
     size_t text = 0;
     for (int c = 0; c < nfields; ++c) {
         if (!fieldname[c]) return fail(MDC_ERR_ARG, "field %d: name is NULL", c);

@@ -432,9 +432,9 @@ __global__ __launch_bounds__(FMT_BLOCK) void format_kernel(const FormatParams P)
 
 // info[0] = sum of the columns' last offsets, info[1] = sum of their first offsets,
 // info[2] = 1 when a column's last offset passes the end of its arena (nbytes may be null)
-__global__ __launch_bounds__(128) void format_prep_kernel(const uint32_t *const *off, const uint64_t *nbytes,
+__global__ __launch_bounds__(256) void format_prep_kernel(const uint32_t *const *off, const uint64_t *nbytes,
                                                           uint32_t ncols, uint64_t rows, uint64_t *info) {
-    __shared__ uint64_t first[128], last[128];
+    __shared__ uint64_t first[256], last[256];
     __shared__ uint32_t bad;
     const uint32_t c = threadIdx.x;
     if (c == 0) bad = 0;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void scan64_apply(const uint64_t *in, uint64_t
 
 hipError_t launch_format_prep(const uint32_t *const *off, const uint64_t *nbytes, uint32_t ncols, uint64_t rows,
                               uint64_t *info, hipStream_t stream) {
-    hipLaunchKernelGGL(format_prep_kernel, dim3(1), dim3(128), 0, stream, off, nbytes, ncols, rows, info);
+    hipLaunchKernelGGL(format_prep_kernel, dim3(1), dim3(256), 0, stream, off, nbytes, ncols, rows, info);
     return hipGetLastError();
 }
 

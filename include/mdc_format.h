@@ -29,7 +29,7 @@ typedef struct mdc_text mdc_text;
  * as the C string the reference prints with "%s": cut at its first NUL byte, and at
  * fieldlen[i] bytes when fieldlen[i] > 0 (the fetch buffer of
  * sqlstatement::bindout(pos,string&,len) holds len bytes, public/db/oracle/_ooci.cpp:622-627).
- * fieldlen may be NULL (no cut).  1..128 fields, names of 1..255 bytes, at most 12 KiB of tag
+ * fieldlen may be NULL (no cut).  1..256 fields, names of 1..255 bytes, at most 12 KiB of tag
  * text (2 x name + 5 bytes per field) in all. */
 int mdc_formatter_create(const char *const *fieldname, const int *fieldlen, int nfields, int device,
                          mdc_formatter **out);

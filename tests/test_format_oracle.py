@@ -99,7 +99,7 @@ def test_formatter_argument_checks_need_no_gpu():
     h = ctypes.c_void_p()
     one = (ctypes.c_char_p * 1)(b"a")
     assert L.mdc_formatter_create(one, None, 0, 0, ctypes.byref(h)) == capi.MDC_ERR_ARG
-    assert L.mdc_formatter_create(one, None, 129, 0, ctypes.byref(h)) == capi.MDC_ERR_ARG
+    assert L.mdc_formatter_create(one, None, 257, 0, ctypes.byref(h)) == capi.MDC_ERR_ARG
     assert L.mdc_formatter_create(None, None, 1, 0, ctypes.byref(h)) == capi.MDC_ERR_ARG
     assert L.mdc_formatter_create(one, None, 1, 0, None) == capi.MDC_ERR_ARG
     empty = (ctypes.c_char_p * 1)(b"")

@@ -97,6 +97,10 @@ def test_longest_names_and_most_fields(port):
     names = [("n%03d" % i) + "x" * 40 for i in range(128)]
     rows = cases.random_rows(11, 70, 128, maxlen=4)
     check_against(port, names, None, rows, 9, "128 fields")
+    names = ["n%03d" % i + "x" * (i % 19) for i in range(256)]
+    rows = cases.random_rows(13, 300, 256, maxlen=6)
+    check_against(port, names, None, rows, 0, "256 fields")
+    check_against(port, names, [(0, 2, 5)[i % 3] for i in range(256)], rows, 40, "256 fields, cut")
     check_against(port, ["y" * 255, "z"], None, cases.random_rows(12, 300, 2, maxlen=9), 0, "255-byte name")
 
 
