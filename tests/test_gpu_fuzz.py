@@ -105,6 +105,45 @@ def test_random_wide_schema(port, seed, utc):
         p.close()
 
 
+def _marks_overlap(data: bytes, mark: bytes) -> bool:
+    """Do two occurrences of `mark` + newline lie within one mark's length of each other?"""
+    pat, el, ends, at = mark + b"\n", len(mark), [], 0
+    while True:
+        at = data.find(pat, at)
+        if at < 0:
+            break
+        ends.append(at + el)  # the newline behind the mark
+        at += 1
+    return any(b - a <= el for a, b in zip(ends, ends[1:]))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_end_marks_with_newlines(port, seed, utc):
+    """End marks that hold newlines over damaged records.  An input in which two occurrences of the mark overlap
+    is refused (and must really hold such a pair); every other input equals the checker's parse."""
+    rng = random.Random(9000 + seed)
+    cols, typed = random_schema(rng, rng.choice([1, 3, 5, 11]))
+    ty = resolve(cols, typed)
+    carry = rng.random() < 0.7
+    endbz = rng.choice(["<end\n/>", "##\n", "\n<e/>", "a\nb\nc", "\n", "<endl/>\n\n", "q\nq"])
+    damage = rng.choice([0.0, 0.02, 0.3])
+    nrec = rng.choice([40, 400, 3000])
+    data = cases.mutated_xml(seed, nrec, cols, endbz=endbz, damage=damage)
+    print("seed", seed, "ncols", len(cols), "carry", carry, "endbz", repr(endbz), "damage", damage, "bytes", len(data), flush=True)
+    p = capi.Parser.xml(cols, typed=ty, endbz=endbz, carry=carry)
+    try:
+        try:
+            got = p.parse_host(data).to_host()
+        except capi.MdcError as e:
+            assert e.code == capi.MDC_ERR_ARG and "overlap" in str(e), e
+            assert _marks_overlap(bytes(data), endbz.encode()), "refused without an overlapping pair"
+            return
+        assert not _marks_overlap(bytes(data), endbz.encode()), "an overlapping pair went unnoticed"
+        assert_batches_equal(got, port.parse_xml(data, cols, typed=ty, endbz=endbz, carry=carry), f"seed {seed}")
+    finally:
+        p.close()
+
+
 @pytest.mark.parametrize("delta", [-17, -1, 0, 1, 16, 4095])
 def test_input_sizes_around_tile_multiples(port, delta):
     """Inputs that end just before, at and just behind a tile boundary (16 KiB), terminated or not."""
