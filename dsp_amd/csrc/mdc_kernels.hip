@@ -174,7 +174,7 @@ enum {
     MS_LAST = 0,    // look-behind: LDS index of the last terminator in front of the tile
     MS_HASNUL = 1,
     MS_STAGED = 2,
-    MS_LBCNT = 3,   // events found in the look-behind region
+    MS_LBCNT = 3,   // delimited mode: separators of the first record that lie in the look-behind
     MS_WTOT = 4,    // 4 words: per-wave totals of the rank/event scan
     MS_NOMAP = 9,   // sizing pass: a cell does not fit a map word
     MS_IRR = 10,    // sizing pass: a record of the tile does not follow the tag template
@@ -1793,6 +1793,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         rank_scan();
         s0_li = t0 + 1;
     }
+    // Delimited input with a separator of one byte: the separators of the first record's part in the
+    // look-behind, one chunk per lane of wave 0, each with its place in the tile's list of separators (they
+    // come first in it).  The record is then measured like every other; otherwise one lane walks it while
+    // the block waits, and nearly every tile's first record begins in the look-behind.
+    uint32_t lbsep_m = 0, lbsep_k = 0;
+    bool lbfast = false;  // (block-uniform)
+    if (sepfast && H->sep_len == 1 && tile_start > 0 && s0_li < ts_li && ts_li / CHUNK - s0_li / CHUNK <= 64) {
+        lbfast = true;
+        if (wave == 0) {
+            const int j = s0_li / CHUNK + lane;
+            if (j < ts_li / CHUNK) {
+                lbsep_m = mask16_eq(((const uint4 *)sdata)[j], rep4(H->sep[0]));
+                if (j * CHUNK < s0_li) lbsep_m &= ~0u << (s0_li - j * CHUNK);
+            }
+            const uint32_t cnt = (uint32_t)__builtin_popcount(lbsep_m);
+            const uint32_t incl = wave_incl_scan(cnt);
+            lbsep_k = incl - cnt;
+            if (lane == 63) ms[MS_LBCNT] = incl;
+        }
+    }
     // NUL bytes of the first record's part in the look-behind count as well (a chunk that begins in
     // front of the record may add the record before: the flag only has to be set when a NUL is there)
     if (tile_start > 0) {
@@ -1837,16 +1857,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     if (tid == 0) recend[0] = (uint32_t)(s0_li - 1);
     const uint32_t seplen = H->sep_len;
     // all separators of the tile, in input order (the staging area is not used by the sizing pass)
-    const bool fastcsv = sepfast && nev_tile <= EVCAP + EVCAP / 2 && !ms[MS_SEPOV];
-    const bool slow0 = fastcsv && s0_li < ts_li;  // the first record starts in the look-behind: walked by one lane
+    const uint32_t lbtot = lbfast ? ms[MS_LBCNT] : 0u;  // separators in front of the tile's own in the list
+    const bool fastcsv = sepfast && nev_tile + lbtot <= EVCAP + EVCAP / 2 && !ms[MS_SEPOV];
+    // the first record starts in the look-behind and its separators there were not collected: walked by one lane
+    const bool slow0 = fastcsv && s0_li < ts_li && !lbfast;
     uint32_t *e0 = desc + ncols * RB;             // first separator of every record of the batch (RB + 1 entries)
     if (fastcsv) {
         uint64_t m = em;
-        uint32_t idx = ev_base;
+        uint32_t idx = ev_base + lbtot;
         while (m) {
             const int b = __builtin_ctzll(m);
             m &= m - 1;
             evpos[idx++] = (uint16_t)(my_li + b);
+        }
+        uint32_t m2 = lbsep_m, k = lbsep_k;  // (zero outside wave 0 and without the look-behind part)
+        while (m2) {
+            const int b = __builtin_ctz(m2);
+            m2 &= m2 - 1;
+            evpos[k++] = (uint16_t)((s0_li / CHUNK + lane) * CHUNK + b);
         }
     }
     const int jlb0 = s0_li / CHUNK, jlb1 = ts_li / CHUNK;  // look-behind chunks of the first record
@@ -1920,7 +1948,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                 if (r >= rb0 && r < rb0 + RBn) recend[r - rb0 + 1] = (uint32_t)(my_li + b);
                 // the record behind this terminator starts with the separators that follow it
                 if (fastcsv && r + 1 >= rb0 && r + 1 <= rb0 + RBn)
-                    e0[r + 1 - rb0] = ev_base + (uint32_t)__builtin_popcountll(em & ((1ull << b) - 1));
+                    e0[r + 1 - rb0] = lbtot + ev_base + (uint32_t)__builtin_popcountll(em & ((1ull << b) - 1));
                 if (tmode && r + 1 >= rb0 && r + 1 <= rb0 + RBn)
                     e0t[r + 1 - rb0] = (int16_t)(ev_base + (uint32_t)__builtin_popcountll(em & ((1ull << b) - 1)));
                 ++r;
@@ -2010,7 +2038,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         // ---- E. cells: descriptor, length, typed value
         if (csv && (!fastcsv || (slow0 && rb0 == 0))) {
             // greedy left-to-right separator search, one lane per record (ccmdstr::splittocmd)
-            if ((uint32_t)tid < (fastcsv ? 1u : RBn)) {
+            if ((uint32_t)tid < (fastcsv ? 1u : RBn) && !SKIP(64)) {
                 const uint32_t r = tid;
                 const uint32_t rs = recend[r] + 1, re = recend[r + 1];
                 uint32_t fmw = 0;

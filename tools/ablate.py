@@ -9,8 +9,12 @@ if os.environ.get("MDC_ABLATE_CHILD"):
     sys.path.insert(0, ROOT)
     from dsp_amd import capi, gen, schema
     capi.LIB_PATH = os.path.join(ROOT, "dsp_amd", "libmdc_parse_ablate.so")
-    data, rows = gen.mind_xml(nbytes=1 << 30)
-    p = capi.Parser.xml(schema.ZHOBTMIND)
+    if os.environ.get("MDC_ABLATE_CSV"):  # (the delimited batch instead)
+        data, rows = gen.mind_csv(nbytes=1 << 30)
+        p = capi.Parser.csv(",", 10, typed=schema.MIND_CSV_TYPED)
+    else:
+        data, rows = gen.mind_xml(nbytes=1 << 30)
+        p = capi.Parser.xml(schema.ZHOBTMIND)
     d = capi.DeviceBuffer(data)
     best = None
     for _ in range(6):
