@@ -1793,19 +1793,48 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         rank_scan();
         s0_li = t0 + 1;
     }
-    // Delimited input with a separator of one byte: the separators of the first record's part in the
-    // look-behind, one chunk per lane of wave 0, each with its place in the tile's list of separators (they
-    // come first in it).  The record is then measured like every other; otherwise one lane walks it while
-    // the block waits, and nearly every tile's first record begins in the look-behind.
+    // Delimited input whose separators are found with byte masks: the separators of the first record's part
+    // in the look-behind, one chunk per lane of wave 0, each with its place in the tile's list of separators
+    // (they come first in it).  The record is then measured like every other; otherwise one lane walks it
+    // while the block waits, and nearly every tile's first record begins in the look-behind.
     uint32_t lbsep_m = 0, lbsep_k = 0;
     bool lbfast = false;  // (block-uniform)
-    if (sepfast && H->sep_len == 1 && tile_start > 0 && s0_li < ts_li && ts_li / CHUNK - s0_li / CHUNK <= 64) {
+    if (sepfast && tile_start > 0 && s0_li < ts_li && ts_li / CHUNK - s0_li / CHUNK <= 64) {
         lbfast = true;
         if (wave == 0) {
             const int j = s0_li / CHUNK + lane;
             if (j < ts_li / CHUNK) {
                 lbsep_m = mask16_eq(((const uint4 *)sdata)[j], rep4(H->sep[0]));
                 if (j * CHUNK < s0_li) lbsep_m &= ~0u << (s0_li - j * CHUNK);
+            }
+            const uint32_t sl = H->sep_len;
+            if (sl > 1 && j < ts_li / CHUNK) {
+                // several bytes: every match of the first byte compared in full; two matches that overlap
+                // leave the tile to the walk, as for the tile's own bytes (classification above)
+                const uint32_t want = (uint32_t)H->sep[0] | ((uint32_t)H->sep[1] << 8) | ((uint32_t)H->sep[2] << 16) |
+                                      ((uint32_t)H->sep[3] << 24);
+                const uint32_t care = sl >= 4 ? ~0u : (1u << (8 * sl)) - 1;
+                auto match_at = [&](int li) {
+                    uint32_t w0, w1;
+                    lds_bytes8(sdata + li, w0, w1);
+                    return ((w0 ^ want) & care) == 0;
+                };
+                uint32_t t = lbsep_m, full = 0;
+                while (t) {
+                    const int b = __builtin_ctz(t);
+                    t &= t - 1;
+                    if (match_at(j * CHUNK + b)) full |= 1u << b;
+                }
+                lbsep_m = full;
+                uint32_t close = full << 1;
+                if (sl > 2) close |= full << 2;
+                if (sl > 3) close |= full << 3;
+                bool overlap = (full & close) != 0;
+                const uint32_t low = full & ((1u << (sl - 1)) - 1);
+                if (low)
+                    for (int d = 1; d < (int)sl; ++d)
+                        if (j * CHUNK - d >= s0_li && (low & ((1u << (sl - d)) - 1)) && match_at(j * CHUNK - d)) overlap = true;
+                if (overlap) ms[MS_SEPOV] = 1;
             }
             const uint32_t cnt = (uint32_t)__builtin_popcount(lbsep_m);
             const uint32_t incl = wave_incl_scan(cnt);
