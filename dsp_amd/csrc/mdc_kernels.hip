@@ -1994,7 +1994,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             bool ok = true;
             // ... and event k must repeat the sample's event k: the first record's events in the
             // look-behind (first batch only) ...
-            if (rb0 == 0 && wave == 0) {
+            if (rb0 == 0 && wave == 0 && !SKIP(128)) {
                 uint32_t m = lbm, k = lbk;
                 while (m) {
                     const uint32_t b = __builtin_ctz(m);

@@ -1,5 +1,5 @@
 """Diagnostic: kernel time with phases switched off (libmdc_parse_ablate.so, MDC_DEBUG_SKIP bits:
-1 = tag events, 2 = cells, 4 = sizing pass ends behind classification and scan, 8 = behind its loads, 16 = emit kernel without its columns, 32 = emit kernel without the columns' stores; one-pass parse (MDC_ONE_PASS=1 in the environment): 1024 = no waiting for the columns' places, 2048 = none for the rows'; MDC_NO_MAP=1 sends every tile through the full write kernel).  Outputs are wrong by construction; only the times matter."""
+1 = tag events, 2 = cells, 4 = sizing pass ends behind classification and scan, 8 = behind its loads, 16 = emit kernel without its columns, 32 = emit kernel without the columns' stores, 64 = delimited sizing pass without the one-lane walk of a record (MDC_ABLATE_CSV=1 parses the delimited batch), 128 = tagged sizing pass without wave 0's compare of the first record's tags in the look-behind; one-pass parse (MDC_ONE_PASS=1 in the environment): 1024 = no waiting for the columns' places, 2048 = none for the rows'; MDC_NO_MAP=1 sends every tile through the full write kernel).  Outputs are wrong by construction; only the times matter."""
 import os
 import subprocess
 import sys
