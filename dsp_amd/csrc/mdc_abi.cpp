@@ -214,6 +214,7 @@ struct mdc_parser {
     uint32_t *d_status = nullptr;
     uint32_t *d_tmpl = nullptr;     // tag template (see TMPL_MAX): built from the first input, kept while the
     uint32_t tmpl_sample = 0;       // the record the next template is taken from (cycles when tiles do not follow)
+    int tmpl_fail = 0, tmpl_rest = 0;  // parses in a row whose tiles mostly left the template; parses to go without one
     bool tmpl_valid = false;        // inputs follow it (any template of this schema gives right results: a tile
                                     // whose records differ takes the table lookup), rebuilt when many tiles do not
     uint32_t *d_hdr = nullptr;      // per tile: cell map slot, first record start
@@ -1112,6 +1113,13 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
         P.map_cap = P.map_stride = 0;
     }
     if (p->mark_nl) P.use_tmpl = 0;  // (a template's tag texts hold no newline; every tile takes the table lookup)
+    // Records of several shapes (a field that is there in some and not in others): most tiles then hold a record
+    // that leaves any template, and the compare they all try first is lost time (a third of the sizing pass).
+    // After two such parses in a row the next sixteen go without a template; then it is tried again.
+    if (P.use_tmpl && p->tmpl_rest > 0) {
+        --p->tmpl_rest;
+        P.use_tmpl = 0;
+    }
     for (int t : p->typed)
         if (t == MDC_T_TIME || t == MDC_T_F32) P.special_cols = 1;
 #ifdef MDC_ABLATE
@@ -1122,6 +1130,7 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
 #endif
     mdc_timing &t = p->timing;
     t.one_pass = t.one_pass_redone = 0;
+    t.lookup_tiles = p->mode == MODE_XML && !P.use_tmpl ? (int)ntiles : 0;  // (without a template every tile takes the lookup)
 
     // One pass where the previous parse left what it needs: a template the input followed, the first
     // look-behind level, and (for a new batch) the sizes to expect.
@@ -1178,6 +1187,13 @@ static int parse_impl(mdc_parser *p, const void *d_data, size_t n, const mdc_out
                 p->tmpl_sample = (p->tmpl_sample + 1) % 4;
             }
             p->timing.lookup_tiles = (int)left;
+            if (ntiles >= 64) {  // (a small input says little: its first tile, with the file's head, never follows)
+                p->tmpl_fail = left * 2 > ntiles ? p->tmpl_fail + 1 : 0;
+                if (p->tmpl_fail >= 2) {
+                    p->tmpl_fail = 0;
+                    p->tmpl_rest = 16;
+                }
+            }
         }
         nlong = (uint32_t)p->h_report[1];
         if ((size_t)nlong * 64 > ntiles && p->lb_level < 2) {

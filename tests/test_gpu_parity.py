@@ -1051,3 +1051,34 @@ def test_overlapping_end_marks_are_refused(port):
         good = b"<a>1</a>" + mark.encode() + b"\n<a>2</a>" + mark.encode() + b"\n"
         assert_batches_equal(p.parse_host(good).to_host(), port.parse_xml(good, cases.SMALL, endbz=mark), f"after a refusal, {mark!r}")
         p.close()
+
+
+def test_records_of_two_shapes_stop_the_template_attempts(port):
+    """Every third record lacks a field, so nearly every tile holds a record that leaves any template: after two
+    such parses the parser goes without a template for a while (the compare every tile tries first is lost
+    time), and takes it up again later.  The cells are the checker's throughout."""
+    import re
+    data, n = gen.mind_xml(nbytes=3 << 20)
+    recs = data.tobytes().split(b"<endl/>\n")
+    for i in range(0, len(recs) - 1, 3):
+        recs[i] = re.sub(rb"<wd>[^<]*</wd>", b"", recs[i])
+    two = np.frombuffer(b"<endl/>\n".join(recs), dtype=np.uint8)
+    exp = port.parse_xml(two, schema.ZHOBTMIND)
+    ntiles = (two.size + 16383) // 16384
+    p = capi.Parser.xml(schema.ZHOBTMIND)
+    seen = []
+    for k in range(22):
+        got = p.parse_host(two).to_host()
+        if k in (0, 1, 2, 3, 18, 19, 21):
+            assert_batches_equal(got, exp, f"parse {k}")
+        seen.append(p.timing().lookup_tiles)
+    assert seen[0] > ntiles // 2 and seen[1] > ntiles // 2      # tried and left by most tiles, twice
+    assert seen[2:18] == [ntiles] * 16                           # sixteen parses without a template
+    assert seen[18] > ntiles // 2                                # (tried again: every tile holds a short record)
+    # a regular input in between is parsed right as well, and takes the template up again once the rest is over
+    reg = port.parse_xml(data, schema.ZHOBTMIND)
+    for k in range(20):
+        got = p.parse_host(data).to_host()
+    assert_batches_equal(got, reg, "regular input afterwards")
+    assert p.timing().lookup_tiles <= 2
+    p.close()
